@@ -1,0 +1,291 @@
+"""CPU oracle for the differentiable point-cloud projection path.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+(pytorch-unsup-pc_amd/) never does and fails loudly without its HIP library.
+
+What it is: an fp64 torch-CPU restatement of the reference's algorithm, stage by stage, using the same
+ATen operator classes the reference uses (accumulating index_put_ for the 8 trilinear corners, three
+zero-padded 1-D conv3d passes, clamp/log/cumsum/exp for the ray march), so that (i) autograd of this
+module is the reference's backward and (ii) timing it on the GPU box's host stands in for "the reference's
+PyTorch CPU path" (the reference itself cannot travel).
+
+Parity is PINNED: tests/test_oracle_golden.py checks every function here against golden vectors produced by
+importing and running the reference in the build container (tests/golden/make_golden.py, fixtures F1-F9),
+including the two seed-0 script bodies the reference ships (dpc/run/pc_project_test.py,
+dpc/run/pc_full_proj_test.py).
+
+Reference lines are cited per function as <file>:<lines> relative to the reference root.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+F64 = torch.float64
+
+
+# --------------------------------------------------------------------------------------------------
+# Gaussian kernels                                  dpc/util/gauss_kernel.py:5-11, 27-32, 35-55
+# --------------------------------------------------------------------------------------------------
+def gauss_kernel_1d(l, sig):
+    """g[x] = exp(-x^2 / 2 sig^2) / sum, x = -(l//2) .. l//2 (odd l), built in fp32 like the reference
+    (dpc/util/gauss_kernel.py:5-11: torch.arange(-l // 2 + 1., l // 2 + 1) is a float32 tensor)."""
+    lo = float((-l) // 2) + 1.0
+    hi = l // 2 + 1
+    x = torch.arange(lo, hi)  # float32
+    k = torch.exp(-x ** 2 / (2.0 * sig ** 2))
+    return k / k.sum()
+
+
+def smoothing_kernel_lengths(cfg):
+    """(fsz_xy, fsz_z, z_ratio) per dpc/util/gauss_kernel.py:36-45."""
+    fsz = cfg.pc_gauss_kernel_size
+    if cfg.vox_size_z != -1:
+        ratio = cfg.vox_size_z / cfg.vox_size
+        fz = int(np.floor(fsz * ratio))
+        if fz % 2 == 0:
+            fz += 1
+        return fsz, fz, ratio
+    return fsz, fsz, 1.0
+
+
+def smoothing_kernel(cfg, sigma):
+    """Three 5-D kernels [1,1,1,1,k] (W), [1,1,1,k,1] (H), [1,1,kz,1,1] (D): dpc/util/gauss_kernel.py:35-55.
+    For vox_size_z != vox_size the reference's reshape (:49) raises; the intended kernel (length fsz_z,
+    sigma*ratio) is produced instead -- pinned by fixture f4 'z8' which builds it from the reference's
+    gauss_kernel_1d."""
+    fsz, fz, ratio = smoothing_kernel_lengths(cfg)
+    k = gauss_kernel_1d(fsz, sigma)
+    kz = k if (fz == fsz and ratio == 1.0) else gauss_kernel_1d(fz, sigma * ratio)
+    if cfg.vox_size_z == -1 and not cfg.pc_separable_gauss_filter:
+        raise NotImplementedError("pc_separable_gauss_filter: false leaves `kernel` unbound in the reference")
+    return [k.reshape(1, 1, 1, 1, fsz), k.reshape(1, 1, 1, fsz, 1), kz.reshape(1, 1, fz, 1, 1)]
+
+
+# --------------------------------------------------------------------------------------------------
+# Quaternion rotation                               dpc/util/quaternion.py:69-86, 89-92, 110-132
+# --------------------------------------------------------------------------------------------------
+def _hamilton(a, b):
+    """(w,x,y,z) Hamilton product, dpc/util/quaternion.py:79-85."""
+    aw, ax, ay, az = a.unbind(-1)
+    bw, bx, by, bz = b.unbind(-1)
+    return torch.stack((aw * bw - ax * bx - ay * by - az * bz,
+                        aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by + ay * bw + az * bx - ax * bz,
+                        aw * bz + az * bw + ax * by - ay * bx), dim=-1)
+
+
+def quaternion_rotate(pc, q):
+    """p' = vec(qn (0,p) qn*), qn = q/|q| with the norm NOT detached (dpc/util/quaternion.py:119-121).
+    The conjugate multiplies by a float64 constant (:91-92), which is why the reference's result is fp64."""
+    qn = (q / q.norm(p=2, dim=-1, keepdim=True)).unsqueeze(1)  # [B,1,4]
+    conj = qn * torch.tensor([1.0, -1.0, -1.0, -1.0], dtype=F64)
+    p4 = F.pad(pc, (1, 0))  # (0, x, y, z)
+    return _hamilton(_hamilton(qn, p4), conj)[..., 1:4]
+
+
+# --------------------------------------------------------------------------------------------------
+# Perspective transform                             dpc/util/point_cloud_to.py:118-178
+# --------------------------------------------------------------------------------------------------
+def pc_perspective_transform(cfg, point_cloud, transform, predicted_translation=None, focal_length=None):
+    """out = (z, y, x) with z = p'_0 (+t_0 - t_0), y = f p'_1 / (p'_0 + d), x = f p'_2 / (p'_0 + d),
+    p' = R(q)p (+ t).  Quaternion branch only (:135-148,169-177); the matrix branch (:149-167) is broken
+    in the reference (UnboundLocalError)."""
+    if not cfg.pose_quaternion:
+        raise NotImplementedError("pose_quaternion: false is a broken branch in the reference (point_cloud_to.py:153)")
+    d = cfg.camera_distance
+    f = cfg.focal_length if focal_length is None else focal_length.unsqueeze(-1)  # [B,1,1]
+    p = quaternion_rotate(point_cloud, transform)
+    if predicted_translation is not None:
+        p = p + predicted_translation.unsqueeze(1)
+    zc = p[..., 0:1] + d
+    xs = p[..., 2:3] * f / zc
+    ys = p[..., 1:2] * f / zc
+    zs = zc - d
+    if predicted_translation is not None:
+        zs = zs - predicted_translation.unsqueeze(1)[..., 0:1]
+    return torch.cat([zs, ys, xs], dim=2)
+
+
+# --------------------------------------------------------------------------------------------------
+# Trilinear splat                                   dpc/util/point_cloud_to.py:10-87
+# --------------------------------------------------------------------------------------------------
+def grid_dims(cfg):
+    G = cfg.vox_size
+    D = cfg.vox_size_z if cfg.vox_size_z != -1 else G
+    return D, G, G
+
+
+def pointcloud2voxels3d_fast(cfg, pc, rgb=None):
+    """voxels[b, iz+k, iy+j, ix+i] += rr[k]_z rr[j]_y rr[i]_x for the 8 corners of every point whose three
+    coordinates lie in [-1/2, 1/2] (inclusive).  Returns (voxels [B,D,H,W] fp64, None).
+    A point exactly at +1/2 indexes cell G and raises IndexError, as in the reference."""
+    if rgb is not None:
+        raise NotImplementedError("rgb splat is a dead branch in the reference (point_cloud_to.py:64)")
+    D, H, W = grid_dims(cfg)
+    B, N, _ = pc.shape
+    pc = pc.to(F64)
+    inside = ((pc >= -0.5) & (pc <= 0.5)).all(-1).reshape(-1)  # :26-27
+    dims = torch.tensor([D, H, W], dtype=F64)
+    g = (pc + 0.5) * (dims - 1.0)  # :29-30
+    cell = torch.floor(g)
+    frac = (g - cell).reshape(-1, 3)[inside]  # r, :39
+    cell = cell.reshape(-1, 3).long()[inside]
+    b = torch.arange(B).repeat_interleave(N)[inside]
+    wz = (1.0 - frac[:, 0], frac[:, 0])
+    wy = (1.0 - frac[:, 1], frac[:, 1])
+    wx = (1.0 - frac[:, 2], frac[:, 2])
+    vox = torch.zeros(B, D, H, W, dtype=F64)
+    for k in (0, 1):  # :79-83, eight accumulating scatters
+        for j in (0, 1):
+            for i in (0, 1):
+                vox = vox.index_put((b, cell[:, 0] + k, cell[:, 1] + j, cell[:, 2] + i),
+                                    wz[k] * wy[j] * wx[i], accumulate=True)
+    return vox, None
+
+
+# --------------------------------------------------------------------------------------------------
+# Separable Gaussian smoothing                      dpc/util/point_cloud_to.py:90-103
+# --------------------------------------------------------------------------------------------------
+def smoothen_voxels3d(cfg, voxels, kernel):
+    """Three zero-padded stride-1 conv3d passes in list order (W, then H, then D); [B,1,D,H,W] in/out."""
+    if not cfg.pc_separable_gauss_filter:
+        raise NotImplementedError("pc_separable_gauss_filter: false is a dead branch in the reference")
+    for k in kernel:
+        pad = tuple(int(s) // 2 for s in k.shape[2:])
+        voxels = F.conv3d(voxels, k.to(F64), stride=1, padding=pad)
+    return voxels
+
+
+# --------------------------------------------------------------------------------------------------
+# DRC ray termination                               dpc/util/drc.py:48-129, 145-160
+# --------------------------------------------------------------------------------------------------
+def drc_event_probabilities(voxels, cfg):
+    """p [D+1,B,H,W,1]: p_0 = e^eps y_0, p_k = y_k prod_{j<k}(1-y_j), p_D = e^eps prod_j (1-y_j), with
+    y = clamp(v, eps, 1-eps).  The 'log-unity' rows are ones*eps, not zeros (drc.py:59-60,96-100) -- kept."""
+    if not (cfg.drc_logsum and cfg.drc_tf_cumulative):
+        raise NotImplementedError("drc_logsum: false / drc_tf_cumulative: false are dead branches in the reference")
+    eps = cfg.drc_logsum_clip_val
+    v = voxels.to(F64).permute(1, 0, 2, 3, 4)  # [D,B,H,W,1]
+    y = torch.clamp(v, eps, 1.0 - eps)
+    log_occ = torch.log(y)
+    log_free = torch.log(1.0 - y).cumsum(0)
+    unit = torch.full_like(v[:1], eps)
+    return torch.exp(torch.cat([unit, log_free], 0) + torch.cat([log_occ, unit], 0))
+
+
+def drc_projection(voxels, cfg):
+    """silhouette = sum_{k<D} p_k (drc.py:121-127).  Returns (proj [B,H,W,1], p)."""
+    p = drc_event_probabilities(voxels, cfg)
+    return p[:-1].sum(0), p
+
+
+def drc_depth_grid(cfg, z_size):
+    """psi_k = k/D - 1/2 + camera_distance (k<D), psi_D = max_depth (drc.py:145-149)."""
+    i = torch.arange(0, z_size, 1, dtype=F64)
+    return torch.cat([i / z_size - 0.5 + cfg.camera_distance, torch.tensor([cfg.max_depth], dtype=F64)])
+
+
+def drc_depth_projection(p, cfg):
+    """expected depth sum_k p_k psi_k (drc.py:152-160)."""
+    psi = drc_depth_grid(cfg, p.shape[0] - 1).reshape(-1, 1, 1, 1, 1)
+    return (p * psi).sum(0)
+
+
+# --------------------------------------------------------------------------------------------------
+# Full chain                                        dpc/util/point_cloud_to.py:191-263
+# --------------------------------------------------------------------------------------------------
+def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation, all_rgb, kernel=None,
+                            scaling_factor=None, focal_length=None, smooth=True):
+    """CUDA-branch semantics of the reference (smooth=True), or its literal CPU branch, which skips the
+    Gaussian (:206-212), with smooth=False."""
+    if all_rgb is not None:
+        raise NotImplementedError("all_rgb is a dead branch in the reference (point_cloud_to.py:64)")
+    if cfg.ptn_max_projection:
+        raise NotImplementedError("ptn_max_projection: true returns a tuple in the reference (point_cloud_to.py:234)")
+    tr_pc = pc_perspective_transform(cfg, point_cloud, transform, predicted_translation, focal_length)
+    raw, _ = pointcloud2voxels3d_fast(cfg, tr_pc, None)
+    vox = torch.clamp(raw.unsqueeze(1), 0.0, 1.0)
+    if kernel is not None and smooth:
+        vox = smoothen_voxels3d(cfg, vox, kernel)
+    vox = vox.squeeze(1).unsqueeze(-1)  # [B,D,H,W,1]
+    if scaling_factor is not None:
+        vox = torch.clamp(vox * scaling_factor.reshape(-1, 1, 1, 1, 1), 0.0, 1.0)
+    proj, probs = drc_projection(vox, cfg)
+    probs = torch.flip(probs, [2])
+    depth = drc_depth_projection(probs, cfg)
+    proj = torch.flip(proj, [1])
+    return {"proj": proj, "voxels": vox, "tr_pc": tr_pc, "voxels_rgb": None, "proj_rgb": None,
+            "drc_probs": probs, "proj_depth": depth, "voxels_raw": raw}
+
+
+# --------------------------------------------------------------------------------------------------
+# Caller-side pieces used by the harness            dpc/models/model_pc_to.py:59-87, 410-440
+# --------------------------------------------------------------------------------------------------
+def get_smooth_sigma(cfg, global_step):
+    """dpc/models/model_pc_to.py:59-63."""
+    return cfg.pc_relative_sigma + global_step / cfg.max_number_of_steps * (cfg.pc_relative_sigma_end - cfg.pc_relative_sigma)
+
+
+def get_dropout_prob(cfg, global_step):
+    """Linear keep-probability schedule, dpc/models/model_pc_to.py:68-87 (exponential branch calls
+    torch.log on floats and is dead)."""
+    if not cfg.pc_point_dropout_scheduled:
+        return cfg.pc_point_dropout
+    if cfg.pc_point_dropout_exponential_schedule:
+        raise NotImplementedError("pc_point_dropout_exponential_schedule: true is a dead branch in the reference")
+    k0 = cfg.pc_point_dropout
+    slope = (1.0 - k0) / (cfg.pc_point_dropout_end_step - cfg.pc_point_dropout_start_step)
+    keep = slope * (global_step / cfg.max_number_of_steps) + (k0 - slope * cfg.pc_point_dropout_start_step)
+    return max(min(keep, 1.0), k0)
+
+
+def proj_loss_pose_candidates(gt, pred, num_candidates):
+    """min-of-K silhouette loss (dpc/models/model_pc_to.py:410-440): per sample pick the candidate with the
+    smallest sum of squared differences, loss = sum over winners of (gt-pred)^2 / S.  Returns (loss, argmin)."""
+    S = gt.shape[0]
+    gt_rep = gt.repeat_interleave(num_candidates, dim=0)
+    per = ((gt_rep - pred) ** 2).sum((1, 2, 3)).reshape(S, num_candidates)
+    win = per.argmin(1)
+    mask = F.one_hot(win, num_candidates).reshape(-1, 1, 1, 1).to(pred.dtype)
+    return (((gt_rep - pred) * mask) ** 2).sum() / S, win
+
+
+def mse_sum_loss(proj, gt):
+    """The benchmark loss of SURVEY 8(d): sum (proj-gt)^2 / B."""
+    return ((proj - gt) ** 2).sum() / proj.shape[0]
+
+
+class Cfg(dict):
+    """Attribute dict carrying the hot path's config keys with the reference's defaults
+    (dpc/resources/default_config.yaml:44-89)."""
+    DEFAULTS = dict(vox_size=64, vox_size_z=-1, camera_distance=2.0, focal_length=1.875, pose_quaternion=True,
+                    pc_separable_gauss_filter=True, pc_gauss_kernel_size=11, ptn_max_projection=False,
+                    drc_logsum=True, drc_logsum_clip_val=0.00001, drc_tf_cumulative=True, max_depth=10.0,
+                    pc_relative_sigma=1.0, pc_relative_sigma_end=0.2, max_number_of_steps=600000,
+                    pc_point_dropout=1.0, pc_point_dropout_scheduled=True,
+                    pc_point_dropout_exponential_schedule=False, pc_point_dropout_end_step=1.0,
+                    pc_point_dropout_start_step=0.0, pose_predict_num_candidates=1,
+                    pc_rgb_stop_points_gradient=False, pc_rgb_divide_by_occupancies=False,
+                    pc_rgb_clip_after_conv=False)
+
+    def __init__(self, **kw):
+        super().__init__(self.DEFAULTS)
+        self.update(kw)
+
+    __getattr__ = dict.__getitem__
+    __setattr__ = dict.__setitem__
+
+
+def synth_inputs(B, N, G, seed, with_t=False, with_f=False):
+    """Synthetic inputs of SURVEY.md 8(d) (same generator calls as tests/golden/make_golden.py)."""
+    g = torch.Generator().manual_seed(seed)
+    pc = (torch.tanh(0.5 * torch.randn(B, N, 3, generator=g)) / 2).float()
+    q = torch.randn(B, 4, generator=g).float()
+    s = (0.5 + 0.5 * torch.rand(B, 1, generator=g)).float()
+    mask = (torch.rand(B, 1, 2 * G, 2 * G, generator=g) > 0.5).double()
+    gt = torch.nn.AvgPool2d(2)(mask).permute(0, 2, 3, 1).contiguous()
+    t = (0.05 * torch.randn(B, 3, generator=g)).float() if with_t else None
+    f = (1.875 + 0.2 * torch.randn(B, 1, generator=g)).float() if with_f else None
+    return pc, q, s, gt, t, f
