@@ -1,0 +1,150 @@
+/*
+ * dpc_render.h -- C ABI of libdpc_render.so: the differentiable point-cloud projection of
+ * NiteshBharadwaj/pytorch-unsup-pc as hand-written HIP kernels for MI355X (gfx950).
+ *
+ * The reference has no native code and no FFI: its hot path is Python calling ATen
+ * (SURVEY.md section 2b).  The entry points below are therefore what a binding for that path would bind --
+ * one call per reference function, plus the fused forward/backward that replaces the whole of
+ * pointcloud_project_fast and its autograd graph.  Each entry cites the reference code it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; all pointers are DEVICE pointers unless named host_*;
+ *   - every buffer is allocated by the caller; the library never allocates device memory and never
+ *     synchronises the stream (so calls can be captured into a hipGraph);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
+ *   - return value: DPC_OK (0) or a negative DPC_ERR_* code; dpc_strerror() names it;
+ *   - re-entrant, no global state; arithmetic type fp32 (the ray-march transmittance product runs in fp64
+ *     registers); tensors are dense row-major with the shapes stated per argument;
+ *   - optional inputs (t, f, s) and optional outputs are NULL when absent.
+ *
+ * Grid: D x H x W voxels (D = vox_size_z or vox_size, H = W = vox_size), voxel (z,y,x) of cloud b at
+ * [((b*D + z)*H + y)*W + x].  Point clouds are [B,N,3] xyz, quaternions [B,4] (w,x,y,z) unnormalised.
+ */
+#ifndef DPC_RENDER_H
+#define DPC_RENDER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPC_ABI_VERSION 2
+#define DPC_MAX_TAPS 63 /* longest 1-D smoothing kernel accepted (pc_gauss_kernel_size) */
+
+enum {
+  DPC_OK = 0,
+  DPC_ERR_NULL = -1,        /* a required pointer is NULL */
+  DPC_ERR_SHAPE = -2,       /* B, N, D, H, W out of range */
+  DPC_ERR_TAPS = -3,        /* tap count even, negative or > DPC_MAX_TAPS */
+  DPC_ERR_LDS = -4,         /* an H x W plane does not fit the 160 KiB LDS tile (H*W too large) */
+  DPC_ERR_LAUNCH = -5,      /* hipLaunchKernel failed (hipGetLastError has the cause) */
+  DPC_ERR_UNSUPPORTED = -6  /* configuration the reference itself cannot run (dead branch) */
+};
+
+/* Geometry and camera constants of one call (dpc/resources/default_config.yaml:77-89 and the cfg fields
+ * read at dpc/util/point_cloud_to.py:11-15,128-135; dpc/util/drc.py:52-57,148). */
+typedef struct DpcParams {
+  int32_t B;               /* clouds in this call (batch_size * step_size * num_candidates)            */
+  int32_t N;               /* points per cloud                                                          */
+  int32_t D, H, W;         /* voxel grid                                                                */
+  int32_t taps_xy;         /* length of the x/y Gaussian (odd), 0 = no smoothing (kernel=None / CPU branch) */
+  int32_t taps_z;          /* length of the z Gaussian (odd), 0 = no smoothing                          */
+  float camera_distance;   /* cfg.camera_distance                                                        */
+  float focal_length;      /* cfg.focal_length, used when f == NULL                                      */
+  float clip_val;          /* cfg.drc_logsum_clip_val (eps)                                              */
+  float max_depth;         /* cfg.max_depth                                                              */
+} DpcParams;
+
+/* Columns of the per-cloud small-gradient rows written by the backward entry points ([B, DPC_SMALL_COLS]). */
+enum { DPC_COL_DQ = 0, DPC_COL_DS = 4, DPC_COL_DT = 5, DPC_COL_DF = 8, DPC_SMALL_COLS = 12 };
+
+int dpc_abi_version(void);
+const char* dpc_strerror(int code);
+
+/* Words of the clamp mask ([B, D, dpc_mask_words_per_plane] uint64; bit i of a plane = voxel y*W+x == i,
+ * set where the raw splat value v satisfies 0 <= v <= 1, the pass-through set of torch.clamp's backward). */
+size_t dpc_mask_words_per_plane(const DpcParams* p);
+/* Point records written by the locate kernel and consumed by the slab kernels: [B, N, DPC_CELL_INTS] int32
+ * (packed cell index iz<<20|iy<<10|ix or -1, then the three fractional weights as fp32 bit patterns, encoded
+ * so that both r and 1-r keep fp32 relative precision).  Opaque to the caller; saved between fwd and bwd. */
+#define DPC_CELL_INTS 4
+/* First launch of the fused forward on its own: transform (the reference's exact op sequence, see
+ * csrc/dpc_common.h) + cell location.  tr_pc [B,N,3] | NULL, cells [B,N,DPC_CELL_INTS].  Integer/bit-exact
+ * against the reference: the parity tests compare `cells` with records computed from the oracle's fp64 tr_pc. */
+int dpc_locate(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, float* tr_pc,
+               int32_t* cells, void* stream);
+/* Scratch the fused entry points need (one grid-sized fp32 buffer + per-tile partial sums). */
+size_t dpc_workspace_bytes(const DpcParams* p);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Fused hot path: replaces pointcloud_project_fast (dpc/util/point_cloud_to.py:191-263) =
+ * pc_perspective_transform (:118-178) -> pointcloud2voxels3d_fast (:10-87) -> clamp (:201) ->
+ * smoothen_voxels3d (:90-103) -> scale+clamp (:218-222) -> drc_projection (dpc/util/drc.py:114-129) ->
+ * flip (:242), in three launches (locate points in fp64 -> splat+W/H passes in LDS -> z column pass + DRC).
+ *   pc [B,N,3], q [B,4], t [B,3]|NULL, f [B,1]|NULL, s [B,1]|NULL, host_kern_xy[taps_xy], host_kern_z[taps_z]
+ *   (HOST pointers: the tap weights travel as kernel arguments)
+ * outputs
+ *   tr_pc    [B,N,3] (z,y,x) | NULL
+ *   cells    [B,N,DPC_CELL_INTS] point records (saved for backward)
+ *   raw      [B,D,H,W] unclamped splat | NULL (not needed by the backward)
+ *   smoothed [B,D,H,W] grid after clamp + Gaussian, BEFORE the occupancy scale (saved for backward;
+ *            voxels = s ? clamp(s*smoothed,0,1) : smoothed)
+ *   mask     [B,D,words] uint64 clamp mask (saved for backward)
+ *   proj     [B,H,W] silhouette, rows already flipped
+ * ------------------------------------------------------------------------------------------------- */
+int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                    const float* s, const float* host_kern_xy, const float* host_kern_z, float* tr_pc,
+                    int32_t* cells, float* raw, float* smoothed, uint64_t* mask, float* proj, void* workspace,
+                    void* stream);
+
+/* Hand-written backward of the chain above (the reference relies on autograd).
+ *   dproj [B,H,W] gradient w.r.t. the (flipped) silhouette
+ * outputs
+ *   dpc    [B,N,3]
+ *   dsmall [B,DPC_SMALL_COLS]: dq at cols 0-3, ds at 4, dt at 5-7, df at 8 (ds/dt/df only meaningful when
+ *          the matching input was given); fully overwritten, needs no zeroing by the caller. */
+int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                    const float* s, const float* host_kern_xy, const float* host_kern_z, const int32_t* cells,
+                    const float* smoothed, const uint64_t* mask, const float* dproj, float* dpc, float* dsmall,
+                    void* workspace, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Stage-level entry points (one per reference function), used for the sub-stage API and to cross-check the
+ * fused path.
+ * ------------------------------------------------------------------------------------------------- */
+
+/* pc_perspective_transform, quaternion branch (dpc/util/point_cloud_to.py:118-148,169-178;
+ * dpc/util/quaternion.py:110-132).  out [B,N,3] in (z,y,x) order. */
+int dpc_transform_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                      float* out, void* stream);
+/* dout [B,N,3] -> dpc [B,N,3], dsmall [B,DPC_SMALL_COLS] (dq, dt, df columns; overwritten). */
+int dpc_transform_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                      const float* dout, float* dpc, float* dsmall, void* stream);
+
+/* pointcloud2voxels3d_fast (dpc/util/point_cloud_to.py:10-87): trilinear scatter of already-transformed
+ * points tr [B,N,3] (z,y,x; fp32, or fp64 when tr_is_f64 -- the reference's direct callers pass fp64) into
+ * vox [B,D,H,W] (overwritten).  cells [B,N,DPC_CELL_INTS] is scratch for the point records. */
+int dpc_splat_fwd(const DpcParams* p, const void* tr, int tr_is_f64, int32_t* cells, float* vox, void* stream);
+/* backward of the scatter: gather dvox [B,D,H,W] at the 8 corners -> dtr [B,N,3] (fp32). */
+int dpc_splat_bwd(const DpcParams* p, const void* tr, int tr_is_f64, const float* dvox, float* dtr, void* stream);
+
+/* smoothen_voxels3d (dpc/util/point_cloud_to.py:90-103): zero-padded separable correlation along W, H, D.
+ * `transpose` != 0 applies the adjoint (flipped taps), i.e. the backward.  in/out [B,D,H,W]; tmp same size. */
+int dpc_smooth(const DpcParams* p, const float* host_kern_xy, const float* host_kern_z, int transpose,
+               const float* in, float* out, float* tmp, void* stream);
+
+/* drc_projection / drc_event_probabilities / drc_depth_projection (dpc/util/drc.py:48-129,145-160).
+ * vox [B,D,H,W] -> proj [B,H,W] | NULL, probs [D+1,B,H,W] | NULL, depth [B,H,W] | NULL.
+ * No row flip here (the reference flips in pointcloud_project_fast, point_cloud_to.py:239-242). */
+int dpc_drc_fwd(const DpcParams* p, const float* vox, float* proj, float* probs, float* depth, void* stream);
+/* dproj [B,H,W]|NULL, dprobs [D+1,B,H,W]|NULL, ddepth [B,H,W]|NULL -> dvox [B,D,H,W]. */
+int dpc_drc_bwd(const DpcParams* p, const float* vox, const float* dproj, const float* dprobs,
+                const float* ddepth, float* dvox, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPC_RENDER_H */

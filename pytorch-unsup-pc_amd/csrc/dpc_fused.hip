@@ -1,0 +1,797 @@
+// Fused hot path of the differentiable point-cloud projection for MI355X (gfx950).
+//
+// Replaces pointcloud_project_fast (dpc/util/point_cloud_to.py:191-263 of the reference) and its autograd
+// backward with four launches:
+//
+//   forward   k_splat_hw   one workgroup per (cloud, z-slab): transform the cloud's points, scatter the 8
+//                          trilinear corners into an LDS-resident slab with ds_add_f32, emit the clamp
+//                          mask (1 bit/voxel), clamp, run the W- and H-passes of the Gaussian in LDS and
+//                          store the slab once, coalesced.
+//             k_zcol_fwd   one lane per (cloud, y, x) ray: the whole z column in registers; D-pass of the
+//                          Gaussian, occupancy scale + clamp, DRC transmittance product (fp64 register),
+//                          silhouette written with the row flip folded into the store.
+//   backward  k_zcol_bwd   one lane per ray: DRC backward in closed form, scale/clamp backward (+ ds
+//                          partial sums), adjoint D-pass.
+//             k_gather_hw  one workgroup per (cloud, z-slab + 1 halo plane): adjoint H-/W-passes in LDS,
+//                          clamp mask, trilinear gather of the 8 corners straight from LDS, transform
+//                          backward, wave/block reduction of the quaternion/translation/focal gradients.
+//
+// HBM traffic per cloud: 16 G^3 B forward + 16 G^3 (+1 halo plane per slab) backward + O(N); the raw splat
+// grid never leaves LDS (only its 1-bit clamp mask does).
+#include <math.h>
+#include <string.h>
+
+#include "dpc_common.h"
+
+namespace {
+
+constexpr int kSlabThreads = 1024;
+constexpr int kColThreads = 256;
+constexpr int kL = 16;                               // outputs per thread in the in-LDS line convolutions
+constexpr int kLdsBudget = 160 * 1024 - 4096;        // slab bytes; the rest holds the reduction scratch
+constexpr int kRedFloats = 16 * (kSlabThreads / DPC_WAVE);
+
+__device__ inline int odd_stride(int w) { return w | 1; }  // LDS row stride: odd => conflict-free column walks
+
+// ------------------------------------------------------------------------------------------------------
+// In-LDS separable passes over a slab laid out [nz][H][WP].
+// Every thread owns (line, segment-of-kL-outputs); all windows are read, then a barrier, then written back,
+// so the pass is in place.  Lanes map to consecutive lines (W-pass: stride WP odd; H-pass: consecutive x),
+// which keeps ds_read_b32/ds_write_b32 bank-conflict free.
+// ------------------------------------------------------------------------------------------------------
+template <int RB, bool CLAMP1, class Post>
+__device__ inline void wpass_inplace(float* slab, int nz, int H, int W, int WP, const TapsT<RB>& taps, Post post) {
+  const int nseg = (W + kL - 1) / kL;
+  const int lines = nz * H;
+  const int per_round = blockDim.x / nseg;
+  for (int l0 = 0; l0 < lines; l0 += per_round) {
+    const int li = threadIdx.x % per_round, seg = threadIdx.x / per_round;
+    const int line = l0 + li;
+    const bool act = seg < nseg && line < lines;
+    float v[kL + 2 * RB];
+    if (act) window_load<RB, kL, CLAMP1>(v, slab + line * WP, 1, seg * kL, W);
+    __syncthreads();
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < kL; ++j) {
+        const int x = seg * kL + j;
+        if (x < W) slab[line * WP + x] = post(line, x, window_dot<RB, kL>(v, taps, j));
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int RB, class Store>
+__device__ inline void hpass(float* slab, int nz, int H, int W, int WP, const TapsT<RB>& taps, Store store) {
+  const int nseg = (H + kL - 1) / kL;
+  const int lines = nz * W;
+  const int per_round = blockDim.x / nseg;
+  for (int l0 = 0; l0 < lines; l0 += per_round) {
+    const int li = threadIdx.x % per_round, seg = threadIdx.x / per_round;
+    const int line = l0 + li;
+    const bool act = seg < nseg && line < lines;
+    const int z = line / W, x = line - z * W;
+    float v[kL + 2 * RB];
+    if (act) window_load<RB, kL, false>(v, slab + z * H * WP + x, WP, seg * kL, H);
+    __syncthreads();
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < kL; ++j) {
+        const int y = seg * kL + j;
+        if (y < H) store(z, y, x, window_dot<RB, kL>(v, taps, j));
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Forward 0: per-point transform (reference-exact op sequence) + cell location in fp64, once per point.          grid (ceil(N/256), B)
+//   SRC = 0: pc/q/t/f -> camera transform (pc_perspective_transform), optional tr_pc output
+//   SRC = 1: points are already transformed, fp32 (z,y,x);  SRC = 2: same, fp64
+// ------------------------------------------------------------------------------------------------------
+template <int SRC>
+__global__ __launch_bounds__(256) void k_locate(DpcParams P, const void* __restrict__ pts, const float* __restrict__ q,
+                                                const float* __restrict__ t, const float* __restrict__ f,
+                                                float* __restrict__ tr_pc, PointRec* __restrict__ recs) {
+  const int b = blockIdx.y;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P.N) return;
+  const size_t idx = (size_t)b * P.N + i;
+  double Z, Y, X;
+  if (SRC == 0) {
+    const CameraRef cam = load_camera_ref(P, q, t, f, b);
+    const float* p = static_cast<const float*>(pts) + idx * 3;
+    project_point_ref(cam, p[0], p[1], p[2], Z, Y, X);
+    if (tr_pc != nullptr) {
+      tr_pc[idx * 3 + 0] = (float)Z; tr_pc[idx * 3 + 1] = (float)Y; tr_pc[idx * 3 + 2] = (float)X;
+    }
+  } else if (SRC == 1) {
+    const float* p = static_cast<const float*>(pts) + idx * 3;
+    Z = p[0]; Y = p[1]; X = p[2];
+  } else {
+    const double* p = static_cast<const double*>(pts) + idx * 3;
+    Z = p[0]; Y = p[1]; X = p[2];
+  }
+  recs[idx] = make_record(Z, Y, X, P.D, P.H, P.W);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Forward 1: splat + mask + clamp + W/H Gaussian passes.                          grid (nslab, B)
+//   Tbuf == nullptr: stage-level pointcloud2voxels3d_fast, only `raw` is written.
+// ------------------------------------------------------------------------------------------------------
+template <int RB>
+__global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, const PointRec* __restrict__ recs,
+                                                           TapsT<RB> taps, int Zs, float* __restrict__ raw,
+                                                           float* __restrict__ Tbuf, uint64_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) float slab[];
+  const int D = P.D, H = P.H, W = P.W, N = P.N;
+  const int WP = odd_stride(W);
+  const int b = blockIdx.y, z0 = blockIdx.x * Zs;
+  const int nz = min(Zs, D - z0);
+  const int tid = threadIdx.x, nthr = blockDim.x;
+
+  for (int i = tid; i < nz * H * WP; i += nthr) slab[i] = 0.f;
+  __syncthreads();
+
+  const PointRec* cloud = recs + (size_t)b * N;
+  for (int i = tid; i < N; i += nthr) {
+    const PointRec rec = load_record(cloud, i);
+    if (rec.code < 0) continue;
+    const Cell c = cell_from_record(rec);
+    if (c.iz + 1 < z0 || c.iz >= z0 + nz) continue;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int zz = c.iz + k - z0;
+      if (zz < 0 || zz >= nz) continue;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int yy = c.iy + j;
+        if (yy >= H) continue;
+#pragma unroll
+        for (int i2 = 0; i2 < 2; ++i2) {
+          const int xx = c.ix + i2;
+          if (xx >= W) continue;
+          atomicAdd(&slab[(zz * H + yy) * WP + xx], c.wz[k] * c.wy[j] * c.wx[i2]);  // ds_add_f32
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // clamp mask (bit set <=> raw <= 1; raw >= 0 always) and, when asked for, the raw grid itself
+  {
+    const int HW = H * W, wpp = (HW + 63) / 64;
+    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+    for (int item = wave; item < nz * wpp; item += nw) {
+      const int z = item / wpp, c = item - z * wpp;
+      const int idx = c * 64 + lane;
+      const bool in = idx < HW;
+      const int y = idx / W, x = idx - y * W;
+      const float v = in ? slab[(z * H + y) * WP + x] : 2.f;
+      const unsigned long long bits = __ballot(in && v <= 1.0f);
+      if (mask != nullptr && lane == 0) mask[((size_t)b * D + z0 + z) * wpp + c] = bits;
+      if (raw != nullptr && in) raw[((size_t)b * D + z0 + z) * HW + idx] = v;
+    }
+  }
+  if (Tbuf == nullptr) return;
+
+  float* Tout = Tbuf + ((size_t)b * D + z0) * H * W;
+  if (RB == 0) {  // no smoothing (centre tap 1) or a kernel trimmed to its centre tap: T = w0^2 clamp(raw, 0, 1)
+    const float w2 = taps.w[0] * taps.w[0];
+    for (int i = tid; i < nz * H * W; i += nthr) {
+      const int x = i % W, zy = i / W;
+      Tout[i] = w2 * fminf(slab[zy * WP + x], 1.0f);
+    }
+    return;
+  }
+  wpass_inplace<RB, true>(slab, nz, H, W, WP, taps, [](int, int, float v) { return v; });
+  hpass<RB>(slab, nz, H, W, WP, taps, [&](int z, int y, int x, float v) { Tout[(z * H + y) * W + x] = v; });
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Shared per-voxel DRC pieces (dpc/util/drc.py:48-129)
+// ------------------------------------------------------------------------------------------------------
+struct RayConst {
+  float eps, hi;  // clamp bounds eps, 1-eps
+  float em1;      // e^eps - 1: the reference's "log-unity" rows are eps, not 0
+  float s;        // occupancy scale of this cloud
+  bool has_s;
+};
+
+// eps-derived constants are computed on the host in fp64 and travel as kernel arguments
+struct RayHost {
+  float eps, hi, em1;
+};
+
+__device__ inline RayConst ray_const(const RayHost& h, const float* s, int b) {
+  RayConst r;
+  r.eps = h.eps;
+  r.hi = h.hi;
+  r.em1 = h.em1;
+  r.has_s = s != nullptr;
+  r.s = r.has_s ? s[b] : 1.0f;
+  return r;
+}
+
+__device__ inline float occupancy(const RayConst& r, float v2) {  // scale + clamp (point_cloud_to.py:218-222)
+  return r.has_s ? fminf(fmaxf(r.s * v2, 0.f), 1.f) : v2;
+}
+
+__device__ inline float drc_clamp(const RayConst& r, float v3) { return fminf(fmaxf(v3, r.eps), r.hi); }
+
+// d proj / d v2 for one voxel given the ray's total transmittance; also returns v2 * dL/dv3 * mask for ds.
+// Branch-free: 1/(1-y) via v_rcp_f32 (1 ulp; 1-y >= eps), masks applied with selects.
+__device__ inline float drc_voxel_bwd(const RayConst& r, float v2, float g, float Tf, bool first, float& ds_term) {
+  const float v3 = occupancy(r, v2);
+  const float y = drc_clamp(r, v3);
+  const bool inside = (v3 >= r.eps) & (v3 <= r.hi);
+  float dv3 = g * fmaf(Tf, __builtin_amdgcn_rcpf(1.0f - y), first ? r.em1 : 0.f);
+  dv3 = inside ? dv3 : 0.f;
+  if (!r.has_s) {
+    ds_term = 0.f;
+    return dv3;
+  }
+  const float u = r.s * v2;
+  const bool m = (u >= 0.f) & (u <= 1.f);
+  ds_term = m ? v2 * dv3 : 0.f;
+  return m ? r.s * dv3 : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Forward 2: D-pass + scale/clamp + DRC silhouette, whole z column in registers.   grid (ceil(HW/256), B)
+// ------------------------------------------------------------------------------------------------------
+template <int DD, int RB>
+__global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_fwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf,
+                                                          const float* __restrict__ s, TapsT<RB> taps,
+                                                          float* __restrict__ smoothed, float* __restrict__ proj) {
+  const int HW = P.H * P.W;
+  const int b = blockIdx.y, ray = blockIdx.x * kColThreads + threadIdx.x;
+  if (ray >= HW) return;
+  const RayConst rc = ray_const(rh, s, b);
+  const float* col = Tbuf + (size_t)b * DD * HW + ray;
+  float* out = smoothed + (size_t)b * DD * HW + ray;
+  float c[DD];
+#pragma unroll
+  for (int z = 0; z < DD; ++z) c[z] = col[(size_t)z * HW];
+  double trans = 1.0;
+  float y0 = 0.f;
+#pragma unroll
+  for (int z = 0; z < DD; ++z) {
+    float v2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2 * RB + 1; ++k) {
+      const int zz = z + k - RB;
+      if (zz >= 0 && zz < DD) v2 = fmaf(taps.w[k], c[zz], v2);
+    }
+    out[(size_t)z * HW] = v2;
+    const float y = drc_clamp(rc, occupancy(rc, v2));
+    if (z == 0) y0 = y;
+    trans *= 1.0 - (double)y;
+  }
+  const int yrow = ray / P.W, x = ray - yrow * P.W;
+  proj[(size_t)b * HW + (P.H - 1 - yrow) * P.W + x] = (float)(1.0 - trans + (double)rc.em1 * (double)y0);
+}
+
+// Generic depth / tap count: same arithmetic, column re-read from global (L1/L2 serve the re-reads).
+__global__ __launch_bounds__(kColThreads) void k_zcol_fwd_dyn(DpcParams P, RayHost rh, const float* __restrict__ Tbuf,
+                                                              const float* __restrict__ s, TapsDyn taps,
+                                                              float* __restrict__ smoothed, float* __restrict__ proj) {
+  const int HW = P.H * P.W, D = P.D;
+  const int b = blockIdx.y, ray = blockIdx.x * kColThreads + threadIdx.x;
+  if (ray >= HW) return;
+  const RayConst rc = ray_const(rh, s, b);
+  const float* col = Tbuf + (size_t)b * D * HW + ray;
+  float* out = smoothed + (size_t)b * D * HW + ray;
+  const int R = taps.n > 0 ? (taps.n - 1) / 2 : 0;
+  double trans = 1.0;
+  float y0 = 0.f;
+  for (int z = 0; z < D; ++z) {
+    float v2;
+    if (taps.n == 0) {
+      v2 = col[(size_t)z * HW];
+    } else {
+      v2 = 0.f;
+      for (int k = 0; k < taps.n; ++k) {
+        const int zz = z + k - R;
+        if (zz >= 0 && zz < D) v2 = fmaf(taps.w[k], col[(size_t)zz * HW], v2);
+      }
+    }
+    out[(size_t)z * HW] = v2;
+    const float y = drc_clamp(rc, occupancy(rc, v2));
+    if (z == 0) y0 = y;
+    trans *= 1.0 - (double)y;
+  }
+  const int yrow = ray / P.W, x = ray - yrow * P.W;
+  proj[(size_t)b * HW + (P.H - 1 - yrow) * P.W + x] = (float)(1.0 - trans + (double)rc.em1 * (double)y0);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Backward 1: DRC backward + scale/clamp backward + adjoint D-pass.                grid (ceil(HW/256), B)
+//   Also zeroes the dq/dt/df accumulators that k_gather_hw adds into, and writes this tile's ds partial.
+// ------------------------------------------------------------------------------------------------------
+__device__ inline void zcol_bwd_epilogue(float ds_acc, float* ds_part, float* dsmall, int b) {
+  __shared__ float red[kColThreads / DPC_WAVE];
+  const float w = wave_sum(ds_acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < kColThreads / DPC_WAVE; ++i) tot += red[i];
+    ds_part[(size_t)b * gridDim.x + blockIdx.x] = tot;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)b * DPC_SMALL_COLS + threadIdx.x] = 0.f;
+}
+
+template <int DD, int RB>
+__global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_bwd(DpcParams P, RayHost rh, const float* __restrict__ smoothed,
+                                                          const float* __restrict__ s,
+                                                          const float* __restrict__ dproj, TapsT<RB> taps_adj,
+                                                          float* __restrict__ dT, float* __restrict__ ds_part,
+                                                          float* __restrict__ dsmall) {
+  const int HW = P.H * P.W;
+  const int b = blockIdx.y, ray = blockIdx.x * kColThreads + threadIdx.x;
+  float ds_acc = 0.f;
+  if (ray < HW) {
+    const RayConst rc = ray_const(rh, s, b);
+    const float* col = smoothed + (size_t)b * DD * HW + ray;
+    float c[DD];
+#pragma unroll
+    for (int z = 0; z < DD; ++z) c[z] = col[(size_t)z * HW];
+    double trans = 1.0;
+#pragma unroll
+    for (int z = 0; z < DD; ++z) {
+      trans *= 1.0 - (double)drc_clamp(rc, occupancy(rc, c[z]));
+      if ((z & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    const float Tf = (float)trans;
+    const int yrow = ray / P.W, x = ray - yrow * P.W;
+    const float g = dproj[(size_t)b * HW + (P.H - 1 - yrow) * P.W + x];
+    // Opaque to the optimiser: without it the clamped values and lane masks of all DD voxels computed for
+    // the transmittance are kept live for the loop below (CSE), which spills the column to scratch.
+#pragma unroll
+    for (int z = 0; z < DD; ++z) asm volatile("" : "+v"(c[z]));
+#pragma unroll
+    for (int z = 0; z < DD; ++z) {
+      float term;
+      c[z] = drc_voxel_bwd(rc, c[z], g, Tf, z == 0, term);
+      ds_acc += term;
+      // keep the unrolled division chains from being interleaved across voxels (it spills the column)
+      if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    float* out = dT + (size_t)b * DD * HW + ray;
+#pragma unroll
+    for (int z = 0; z < DD; ++z) {
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2 * RB + 1; ++k) {
+        const int zz = z + k - RB;
+        if (zz >= 0 && zz < DD) acc = fmaf(taps_adj.w[k], c[zz], acc);
+      }
+      out[(size_t)z * HW] = acc;
+      if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  zcol_bwd_epilogue(ds_acc, ds_part, dsmall, b);
+}
+
+__global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHost rh, const float* __restrict__ smoothed,
+                                                              const float* __restrict__ s,
+                                                              const float* __restrict__ dproj, TapsDyn taps_adj,
+                                                              float* __restrict__ dT, float* __restrict__ ds_part,
+                                                              float* __restrict__ dsmall) {
+  const int HW = P.H * P.W, D = P.D;
+  const int b = blockIdx.y, ray = blockIdx.x * kColThreads + threadIdx.x;
+  float ds_acc = 0.f;
+  if (ray < HW) {
+    const RayConst rc = ray_const(rh, s, b);
+    const float* col = smoothed + (size_t)b * D * HW + ray;
+    double trans = 1.0;
+    for (int z = 0; z < D; ++z) trans *= 1.0 - (double)drc_clamp(rc, occupancy(rc, col[(size_t)z * HW]));
+    const float Tf = (float)trans;
+    const int yrow = ray / P.W, x = ray - yrow * P.W;
+    const float g = dproj[(size_t)b * HW + (P.H - 1 - yrow) * P.W + x];
+    const int R = taps_adj.n > 0 ? (taps_adj.n - 1) / 2 : 0;
+    float* out = dT + (size_t)b * D * HW + ray;
+    for (int z = 0; z < D; ++z) {
+      float term;
+      const float own = drc_voxel_bwd(rc, col[(size_t)z * HW], g, Tf, z == 0, term);
+      ds_acc += term;
+      float acc;
+      if (taps_adj.n == 0) {
+        acc = own;
+      } else {
+        acc = 0.f;
+        for (int k = 0; k < taps_adj.n; ++k) {
+          const int zz = z + k - R;
+          if (zz >= 0 && zz < D) {
+            float unused;
+            acc = fmaf(taps_adj.w[k], drc_voxel_bwd(rc, col[(size_t)zz * HW], g, Tf, zz == 0, unused), acc);
+          }
+        }
+      }
+      out[(size_t)z * HW] = acc;
+    }
+  }
+  zcol_bwd_epilogue(ds_acc, ds_part, dsmall, b);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Backward 2: adjoint H/W passes + clamp mask + trilinear gather + transform backward.   grid (nslab, B)
+//   The slab holds cell layers [z0, z0+Zs) plus one halo plane so each point's 8 corners are local.
+// ------------------------------------------------------------------------------------------------------
+template <int RB>
+__global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, const PointRec* __restrict__ recs,
+                                                            const float* __restrict__ pc,
+                                                            const float* __restrict__ q, const float* __restrict__ t,
+                                                            const float* __restrict__ f, TapsT<RB> taps_adj, int Zs,
+                                                            const float* __restrict__ dT,
+                                                            const uint64_t* __restrict__ mask,
+                                                            const float* __restrict__ ds_part, int n_ds_part,
+                                                            float* __restrict__ dpc, float* __restrict__ dsmall) {
+  extern __shared__ __attribute__((aligned(16))) float slab[];
+  const int D = P.D, H = P.H, W = P.W, N = P.N, HW = H * W;
+  const int WP = odd_stride(W);
+  const int b = blockIdx.y, z0 = blockIdx.x * Zs;
+  const int nzp = min(Zs + 1, D - z0);  // planes present (cell layers + halo)
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int wpp = (HW + 63) / 64;
+  float* red = slab + (size_t)(Zs + 1) * H * WP;
+
+  const float* src = dT + ((size_t)b * D + z0) * HW;
+  for (int i = tid; i < nzp * HW; i += nthr) {
+    const int x = i % W, zy = i / W;
+    slab[zy * WP + x] = src[i];
+  }
+  __syncthreads();
+
+  const uint64_t* mrow = mask + ((size_t)b * D + z0) * wpp;
+  if (RB == 0) {
+    const float w2 = taps_adj.w[0] * taps_adj.w[0];
+    for (int i = tid; i < nzp * HW; i += nthr) {
+      const int z = i / HW, r = i - z * HW;
+      const int x = r % W, y = r / W;
+      const bool pass = (mrow[(size_t)z * wpp + (r >> 6)] >> (r & 63)) & 1ull;
+      slab[(z * H + y) * WP + x] = pass ? w2 * slab[(z * H + y) * WP + x] : 0.f;
+    }
+    __syncthreads();
+  } else {
+    hpass<RB>(slab, nzp, H, W, WP, taps_adj, [&](int z, int y, int x, float v) { slab[(z * H + y) * WP + x] = v; });
+    wpass_inplace<RB, false>(slab, nzp, H, W, WP, taps_adj, [&](int line, int x, float v) {
+      const int z = line / H, y = line - z * H;
+      const int bit = y * W + x;
+      return ((mrow[(size_t)z * wpp + (bit >> 6)] >> (bit & 63)) & 1ull) ? v : 0.f;
+    });
+  }
+
+  const Camera cam = load_camera(P, q, t, f, b);
+  CamGrad g;
+  camgrad_zero(g);
+  const float* cloud = pc + (size_t)b * N * 3;
+  float* dcloud = dpc + (size_t)b * N * 3;
+  const PointRec* crecs = recs + (size_t)b * N;
+  for (int i = tid; i < N; i += nthr) {
+    const Cell c = cell_from_record(load_record(crecs, i));
+    const bool mine = c.valid ? (c.iz >= z0 && c.iz < z0 + Zs) : (blockIdx.x == 0);
+    if (!mine) continue;
+    float dpx = 0.f, dpy = 0.f, dpz = 0.f;
+    if (c.valid) {
+      float cv[2][2][2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i2 = 0; i2 < 2; ++i2) {
+            const bool ok = (c.iz + k < D) && (c.iy + j < H) && (c.ix + i2 < W);
+            cv[k][j][i2] = ok ? slab[((c.iz - z0 + k) * H + c.iy + j) * WP + c.ix + i2] : 0.f;
+          }
+      float dgz = 0.f, dgy = 0.f, dgx = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          dgz += (cv[1][a][e] - cv[0][a][e]) * c.wy[a] * c.wx[e];
+          dgy += (cv[a][1][e] - cv[a][0][e]) * c.wz[a] * c.wx[e];
+          dgx += (cv[a][e][1] - cv[a][e][0]) * c.wz[a] * c.wy[e];
+        }
+      const float px = cloud[3 * i + 0], py = cloud[3 * i + 1], pz = cloud[3 * i + 2];
+      const Projected o = project_point(cam, px, py, pz);
+      project_point_bwd(cam, o, px, py, pz, dgz * (float)(D - 1), dgy * (float)(H - 1), dgx * (float)(W - 1), dpx, dpy,
+                        dpz, g);
+    }
+    dcloud[3 * i + 0] = dpx; dcloud[3 * i + 1] = dpy; dcloud[3 * i + 2] = dpz;
+  }
+
+  float vals[13];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) vals[i] = g.m[i];
+  vals[9] = g.dt[0]; vals[10] = g.dt[1]; vals[11] = g.dt[2]; vals[12] = g.df;
+  __syncthreads();  // slab reads done before the scratch tail is reused (it is disjoint, but keep phases apart)
+  block_sum<13>(vals, red);
+  if (tid == 0) {
+    float dq[4];
+    quaternion_grad(cam, vals, dq);
+    float* row = dsmall + (size_t)b * DPC_SMALL_COLS;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) atomicAdd(row + DPC_COL_DQ + i, dq[i]);
+    if (t != nullptr)
+      for (int i = 0; i < 3; ++i) atomicAdd(row + DPC_COL_DT + i, vals[9 + i]);
+    if (f != nullptr) atomicAdd(row + DPC_COL_DF, vals[12]);
+    if (blockIdx.x == 0) {
+      float ds = 0.f;
+      for (int i = 0; i < n_ds_part; ++i) ds += ds_part[(size_t)b * n_ds_part + i];
+      row[DPC_COL_DS] = ds;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------------------------
+struct TapPlan {
+  int taps;    // original length
+  int radius;  // effective radius after dropping negligible outer taps
+  int bucket;  // compile-time radius bucket, -1 = needs the generic kernel
+};
+
+// Outer taps whose total |weight| is below 1e-10 of the kernel's mass change no fp32 result at the 1e-5
+// parity tolerance (inputs are clamped to [0,1]); for sigma_rel = 0.64 this keeps 9 of 21 taps.
+TapPlan plan_taps(const float* k, int taps) {
+  TapPlan p{taps, 0, 0};
+  if (taps <= 0) return p;
+  const int c = (taps - 1) / 2;
+  double total = 0.0;
+  for (int i = 0; i < taps; ++i) total += fabs((double)k[i]);
+  int r = c;
+  double dropped = 0.0;
+  while (r > 0) {
+    const double d = fabs((double)k[c - r]) + fabs((double)k[c + r]);
+    if (dropped + d > 1e-10 * total) break;
+    dropped += d;
+    --r;
+  }
+  p.radius = r;
+  static const int buckets[] = {0, 1, 2, 4, 6, 10, 15};
+  p.bucket = -1;
+  for (int bk : buckets)
+    if (r <= bk) {
+      p.bucket = bk;
+      break;
+    }
+  return p;
+}
+
+template <int RB>
+TapsT<RB> make_taps(const float* k, const TapPlan& p, bool flip) {
+  TapsT<RB> t;
+  for (int i = 0; i < 2 * RB + 1; ++i) t.w[i] = 0.f;
+  if (p.taps > 0) {
+    const int c = (p.taps - 1) / 2;
+    for (int o = -p.radius; o <= p.radius; ++o) t.w[RB + o] = k[c + (flip ? -o : o)];
+  } else {
+    t.w[RB] = 1.f;
+  }
+  return t;
+}
+
+TapsDyn make_taps_dyn(const float* k, int taps, bool flip) {
+  TapsDyn t;
+  t.n = taps;
+  for (int i = 0; i < DPC_MAX_TAPS; ++i) t.w[i] = 0.f;
+  for (int i = 0; i < taps; ++i) t.w[i] = k[flip ? taps - 1 - i : i];
+  return t;
+}
+
+int validate(const DpcParams* p) {
+  if (p == nullptr) return DPC_ERR_NULL;
+  if (p->B < 0 || p->N < 0 || p->D < 1 || p->H < 1 || p->W < 1) return DPC_ERR_SHAPE;
+  if (p->D > 1024 || p->H > 1024 || p->W > 1024 || p->B > 65535) return DPC_ERR_SHAPE;  // 10-bit cell indices
+  for (int taps : {p->taps_xy, p->taps_z})
+    if (taps < 0 || taps > DPC_MAX_TAPS || (taps > 0 && taps % 2 == 0)) return DPC_ERR_TAPS;
+  return DPC_OK;
+}
+
+// planes of an H x W slab that fit the LDS tile
+int planes_fit(const DpcParams* p) { return kLdsBudget / ((p->H * (p->W | 1)) * (int)sizeof(float)); }
+
+int slab_threads(const DpcParams* p) { return (long long)p->H * p->W >= 2048 ? kSlabThreads : 256; }
+
+int col_tiles(const DpcParams* p) { return (p->H * p->W + kColThreads - 1) / kColThreads; }
+
+template <class K>
+int set_lds(K kernel, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)bytes) == hipSuccess
+             ? DPC_OK
+             : DPC_ERR_LAUNCH;
+}
+
+RayHost ray_host(const DpcParams* p) {
+  const double eps = (double)p->clip_val;
+  return RayHost{p->clip_val, (float)(1.0 - eps), (float)expm1(eps)};
+}
+
+int launch_ok() { return hipGetLastError() == hipSuccess ? DPC_OK : DPC_ERR_LAUNCH; }
+
+#define DPC_FOR_BUCKET(bucket, MACRO) \
+  switch (bucket) {                   \
+    case 0: MACRO(0); break;          \
+    case 1: MACRO(1); break;          \
+    case 2: MACRO(2); break;          \
+    case 4: MACRO(4); break;          \
+    case 6: MACRO(6); break;          \
+    case 10: MACRO(10); break;        \
+    case 15: MACRO(15); break;        \
+    default: rc = DPC_ERR_TAPS;       \
+  }
+
+}  // namespace
+
+extern "C" {
+
+size_t dpc_mask_words_per_plane(const DpcParams* p) { return p ? ((size_t)p->H * p->W + 63) / 64 : 0; }
+
+size_t dpc_workspace_bytes(const DpcParams* p) {
+  if (validate(p) != DPC_OK) return 0;
+  const size_t grid = (size_t)p->B * p->D * p->H * p->W * sizeof(float);
+  const size_t parts = (size_t)p->B * col_tiles(p) * sizeof(float);
+  return ((grid + 255) / 256) * 256 + ((parts + 255) / 256) * 256;
+}
+
+int dpc_locate(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, float* tr_pc,
+               int32_t* cells, void* stream) {
+  int rc = validate(p);
+  if (rc != DPC_OK) return rc;
+  if (p->B == 0 || p->N == 0) return DPC_OK;
+  if (!pc || !q || !cells) return DPC_ERR_NULL;
+  hipLaunchKernelGGL(k_locate<0>, dim3((p->N + 255) / 256, p->B), dim3(256), 0, (hipStream_t)stream, *p, (const void*)pc,
+                     q, t, f, tr_pc, reinterpret_cast<PointRec*>(cells));
+  return launch_ok();
+}
+
+// Stage-level splat (pointcloud2voxels3d_fast): locate (fp64) + the same slab kernel, raw grid only.
+int dpc_splat_fwd(const DpcParams* p, const void* tr, int tr_is_f64, int32_t* cells, float* vox, void* stream) {
+  int rc = validate(p);
+  if (rc != DPC_OK) return rc;
+  if (!vox || (p->N > 0 && p->B > 0 && (!tr || !cells))) return DPC_ERR_NULL;
+  if (p->B == 0) return DPC_OK;
+  const int fit = planes_fit(p);
+  if (fit < 1) return DPC_ERR_LDS;
+  hipStream_t st = (hipStream_t)stream;
+  PointRec* recs = reinterpret_cast<PointRec*>(cells);
+  if (p->N > 0) {
+    dim3 gl((p->N + 255) / 256, p->B);
+    if (tr_is_f64)
+      hipLaunchKernelGGL(k_locate<2>, gl, dim3(256), 0, st, *p, tr, nullptr, nullptr, nullptr, nullptr, recs);
+    else
+      hipLaunchKernelGGL(k_locate<1>, gl, dim3(256), 0, st, *p, tr, nullptr, nullptr, nullptr, nullptr, recs);
+    if ((rc = launch_ok()) != DPC_OK) return rc;
+  }
+  const int Zs = std::min(fit, std::max(1, (p->D + 7) / 8));
+  const size_t lds = (size_t)Zs * p->H * (p->W | 1) * sizeof(float);
+  auto kern = k_splat_hw<0>;
+  if ((rc = set_lds(kern, lds)) != DPC_OK) return rc;
+  dim3 grid((p->D + Zs - 1) / Zs, p->B);
+  hipLaunchKernelGGL(kern, grid, dim3(slab_threads(p)), lds, st, *p, (const PointRec*)recs, TapsT<0>{{1.f}}, Zs, vox,
+                     nullptr, nullptr);
+  return launch_ok();
+}
+
+int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                    const float* s, const float* host_kern_xy, const float* host_kern_z, float* tr_pc,
+                    int32_t* cells, float* raw, float* smoothed, uint64_t* mask, float* proj, void* workspace,
+                    void* stream) {
+  int rc = validate(p);
+  if (rc != DPC_OK) return rc;
+  if (!q || !smoothed || !mask || !proj || !workspace) return DPC_ERR_NULL;
+  if (p->N > 0 && p->B > 0 && (!pc || !cells)) return DPC_ERR_NULL;
+  if ((p->taps_xy > 0 && !host_kern_xy) || (p->taps_z > 0 && !host_kern_z)) return DPC_ERR_NULL;
+  if (p->B == 0) return DPC_OK;
+  const TapPlan pxy = plan_taps(host_kern_xy, p->taps_xy), pz = plan_taps(host_kern_z, p->taps_z);
+  if (pxy.bucket < 0) return DPC_ERR_TAPS;  // in-LDS passes need a radius bucket; caller composes the stage ops
+  const int fit = planes_fit(p);
+  if (fit < 1) return DPC_ERR_LDS;
+  const int Zs = std::min(fit, std::max(1, (p->D + 7) / 8));
+  const size_t lds = (size_t)Zs * p->H * (p->W | 1) * sizeof(float);
+  float* Tbuf = static_cast<float*>(workspace);
+  hipStream_t st = (hipStream_t)stream;
+  PointRec* recs = reinterpret_cast<PointRec*>(cells);
+
+  if (p->N > 0) {
+    hipLaunchKernelGGL(k_locate<0>, dim3((p->N + 255) / 256, p->B), dim3(256), 0, st, *p, (const void*)pc, q, t, f, tr_pc,
+                       recs);
+    if ((rc = launch_ok()) != DPC_OK) return rc;
+  }
+
+  dim3 gslab((p->D + Zs - 1) / Zs, p->B);
+#define LAUNCH_SPLAT(RB)                                                                                        \
+  {                                                                                                             \
+    auto kern = k_splat_hw<RB>;                                                                                 \
+    if ((rc = set_lds(kern, lds)) == DPC_OK)                                                                    \
+      hipLaunchKernelGGL(kern, gslab, dim3(slab_threads(p)), lds, st, *p, (const PointRec*)recs,                \
+                         make_taps<RB>(host_kern_xy, pxy, false), Zs, raw, Tbuf, mask);                         \
+  }
+  DPC_FOR_BUCKET(pxy.bucket, LAUNCH_SPLAT)
+#undef LAUNCH_SPLAT
+  if (rc != DPC_OK) return rc;
+  if ((rc = launch_ok()) != DPC_OK) return rc;
+
+  dim3 gcol(col_tiles(p), p->B);
+  const RayHost rh = ray_host(p);
+  bool done = false;
+#define LAUNCH_ZFWD(RB)                                                                                          \
+  {                                                                                                              \
+    const TapsT<RB> tz = make_taps<RB>(host_kern_z, pz, false);                                                  \
+    if (p->D == 32) { hipLaunchKernelGGL((k_zcol_fwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj); done = true; } \
+    else if (p->D == 64) { hipLaunchKernelGGL((k_zcol_fwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj); done = true; } \
+    else if (p->D == 128) { hipLaunchKernelGGL((k_zcol_fwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj); done = true; } \
+  }
+  if (pz.bucket >= 0) { DPC_FOR_BUCKET(pz.bucket, LAUNCH_ZFWD) }
+#undef LAUNCH_ZFWD
+  if (!done) {
+    rc = DPC_OK;
+    hipLaunchKernelGGL(k_zcol_fwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s,
+                       make_taps_dyn(host_kern_z, p->taps_z, false), smoothed, proj);
+  }
+  return launch_ok();
+}
+
+int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                    const float* s, const float* host_kern_xy, const float* host_kern_z, const int32_t* cells,
+                    const float* smoothed, const uint64_t* mask, const float* dproj, float* dpc, float* dsmall,
+                    void* workspace, void* stream) {
+  int rc = validate(p);
+  if (rc != DPC_OK) return rc;
+  if (!q || !smoothed || !mask || !dproj || !dsmall || !workspace) return DPC_ERR_NULL;
+  if (p->N > 0 && p->B > 0 && (!pc || !cells || !dpc)) return DPC_ERR_NULL;
+  if ((p->taps_xy > 0 && !host_kern_xy) || (p->taps_z > 0 && !host_kern_z)) return DPC_ERR_NULL;
+  if (p->B == 0) return DPC_OK;
+  const TapPlan pxy = plan_taps(host_kern_xy, p->taps_xy), pz = plan_taps(host_kern_z, p->taps_z);
+  if (pxy.bucket < 0) return DPC_ERR_TAPS;
+  const int fit = planes_fit(p);
+  if (fit < 2) return DPC_ERR_LDS;
+  const int Zs = std::min(fit - 1, std::max(1, (p->D + 7) / 8));
+  const size_t lds = ((size_t)(Zs + 1) * p->H * (p->W | 1) + kRedFloats) * sizeof(float);
+  float* dT = static_cast<float*>(workspace);
+  const size_t grid_bytes = (((size_t)p->B * p->D * p->H * p->W * sizeof(float) + 255) / 256) * 256;
+  float* ds_part = reinterpret_cast<float*>(static_cast<char*>(workspace) + grid_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int ntile = col_tiles(p);
+  dim3 gcol(ntile, p->B);
+  const RayHost rh = ray_host(p);
+
+  bool done = false;
+#define LAUNCH_ZBWD(RB)                                                                                           \
+  {                                                                                                               \
+    const TapsT<RB> tz = make_taps<RB>(host_kern_z, pz, true);                                                    \
+    if (p->D == 32) { hipLaunchKernelGGL((k_zcol_bwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, tz, dT, ds_part, dsmall); done = true; } \
+    else if (p->D == 64) { hipLaunchKernelGGL((k_zcol_bwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, tz, dT, ds_part, dsmall); done = true; } \
+    else if (p->D == 128) { hipLaunchKernelGGL((k_zcol_bwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, tz, dT, ds_part, dsmall); done = true; } \
+  }
+  if (pz.bucket >= 0) { DPC_FOR_BUCKET(pz.bucket, LAUNCH_ZBWD) }
+#undef LAUNCH_ZBWD
+  if (!done) {
+    rc = DPC_OK;
+    hipLaunchKernelGGL(k_zcol_bwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj,
+                       make_taps_dyn(host_kern_z, p->taps_z, true), dT, ds_part, dsmall);
+  }
+  if ((rc = launch_ok()) != DPC_OK) return rc;
+
+  dim3 gslab((p->D + Zs - 1) / Zs, p->B);
+#define LAUNCH_GATHER(RB)                                                                                        \
+  {                                                                                                              \
+    auto kern = k_gather_hw<RB>;                                                                                 \
+    if ((rc = set_lds(kern, lds)) == DPC_OK)                                                                     \
+      hipLaunchKernelGGL(kern, gslab, dim3(slab_threads(p)), lds, st, *p, reinterpret_cast<const PointRec*>(cells), \
+                         pc, q, t, f, make_taps<RB>(host_kern_xy, pxy, true), Zs, dT, mask, ds_part, ntile, dpc,    \
+                         dsmall);                                                                                \
+  }
+  DPC_FOR_BUCKET(pxy.bucket, LAUNCH_GATHER)
+#undef LAUNCH_GATHER
+  if (rc != DPC_OK) return rc;
+  return launch_ok();
+}
+
+}  // extern "C"

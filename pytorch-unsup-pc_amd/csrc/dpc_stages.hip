@@ -1,0 +1,319 @@
+// Stage-level entry points: one per reference function, for the sub-stage Python API
+// (pc_perspective_transform, pointcloud2voxels3d_fast backward, smoothen_voxels3d, drc_*) and as an
+// independent on-device cross-check of the fused path in dpc_fused.hip.  These favour generality (any grid
+// size, any tap count up to DPC_MAX_TAPS) over fusion; the hot path does not go through them.
+#include <math.h>
+
+#include "dpc_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+int validate(const DpcParams* p) {
+  if (p == nullptr) return DPC_ERR_NULL;
+  if (p->B < 0 || p->N < 0 || p->D < 1 || p->H < 1 || p->W < 1) return DPC_ERR_SHAPE;
+  if (p->D > 1024 || p->H > 1024 || p->W > 1024 || p->B > 65535) return DPC_ERR_SHAPE;  // 10-bit cell indices
+  for (int taps : {p->taps_xy, p->taps_z})
+    if (taps < 0 || taps > DPC_MAX_TAPS || (taps > 0 && taps % 2 == 0)) return DPC_ERR_TAPS;
+  return DPC_OK;
+}
+
+int launch_ok() { return hipGetLastError() == hipSuccess ? DPC_OK : DPC_ERR_LAUNCH; }
+
+// ------------------------------------------------------------------------------------------------------
+// pc_perspective_transform                              dpc/util/point_cloud_to.py:118-178
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_transform_fwd(DpcParams P, const float* __restrict__ pc,
+                                                            const float* __restrict__ q, const float* __restrict__ t,
+                                                            const float* __restrict__ f, float* __restrict__ out) {
+  const int b = blockIdx.y;
+  const CameraRef cam = load_camera_ref(P, q, t, f, b);  // the reference's exact op sequence, rounded once on store
+  const float* cloud = pc + (size_t)b * P.N * 3;
+  float* o3 = out + (size_t)b * P.N * 3;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.N; i += gridDim.x * blockDim.x) {
+    double Z, Y, X;
+    project_point_ref(cam, cloud[3 * i], cloud[3 * i + 1], cloud[3 * i + 2], Z, Y, X);
+    o3[3 * i + 0] = (float)Z; o3[3 * i + 1] = (float)Y; o3[3 * i + 2] = (float)X;
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void k_transform_bwd(DpcParams P, const float* __restrict__ pc,
+                                                            const float* __restrict__ q, const float* __restrict__ t,
+                                                            const float* __restrict__ f,
+                                                            const float* __restrict__ dout, float* __restrict__ dpc,
+                                                            float* __restrict__ dsmall) {
+  __shared__ float red[13 * (kThreads / DPC_WAVE)];
+  const int b = blockIdx.y;
+  const Camera cam = load_camera(P, q, t, f, b);
+  const float* cloud = pc + (size_t)b * P.N * 3;
+  const float* g3 = dout + (size_t)b * P.N * 3;
+  float* d3 = dpc + (size_t)b * P.N * 3;
+  CamGrad g;
+  camgrad_zero(g);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.N; i += gridDim.x * blockDim.x) {
+    const float px = cloud[3 * i], py = cloud[3 * i + 1], pz = cloud[3 * i + 2];
+    const Projected o = project_point(cam, px, py, pz);
+    float dx, dy, dz;
+    project_point_bwd(cam, o, px, py, pz, g3[3 * i], g3[3 * i + 1], g3[3 * i + 2], dx, dy, dz, g);
+    d3[3 * i] = dx; d3[3 * i + 1] = dy; d3[3 * i + 2] = dz;
+  }
+  float vals[13];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) vals[i] = g.m[i];
+  vals[9] = g.dt[0]; vals[10] = g.dt[1]; vals[11] = g.dt[2]; vals[12] = g.df;
+  block_sum<13>(vals, red);
+  if (threadIdx.x == 0) {
+    float dq[4];
+    quaternion_grad(cam, vals, dq);
+    float* row = dsmall + (size_t)b * DPC_SMALL_COLS;
+    for (int i = 0; i < 4; ++i) atomicAdd(row + DPC_COL_DQ + i, dq[i]);
+    for (int i = 0; i < 3; ++i) atomicAdd(row + DPC_COL_DT + i, vals[9 + i]);
+    atomicAdd(row + DPC_COL_DF, vals[12]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// backward of pointcloud2voxels3d_fast: gather the 8 corners from a grid in global memory
+// ------------------------------------------------------------------------------------------------------
+template <class TIN>
+__global__ __launch_bounds__(kThreads) void k_splat_bwd(DpcParams P, const TIN* __restrict__ tr,
+                                                        const float* __restrict__ dvox, float* __restrict__ dtr) {
+  const int D = P.D, H = P.H, W = P.W;
+  const size_t total = (size_t)P.B * P.N;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / P.N);
+    const Cell c = cell_from_record(make_record((double)tr[3 * i], (double)tr[3 * i + 1], (double)tr[3 * i + 2], D, H, W));
+    float dZ = 0.f, dY = 0.f, dX = 0.f;
+    if (c.valid) {
+      const float* gb = dvox + (size_t)b * D * H * W;
+      float cv[2][2][2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const bool ok = (c.iz + k < D) && (c.iy + j < H) && (c.ix + e < W);
+            cv[k][j][e] = ok ? gb[((size_t)(c.iz + k) * H + c.iy + j) * W + c.ix + e] : 0.f;
+          }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          dZ += (cv[1][a][e] - cv[0][a][e]) * c.wy[a] * c.wx[e];
+          dY += (cv[a][1][e] - cv[a][0][e]) * c.wz[a] * c.wx[e];
+          dX += (cv[a][e][1] - cv[a][e][0]) * c.wz[a] * c.wy[e];
+        }
+      dZ *= (float)(D - 1); dY *= (float)(H - 1); dX *= (float)(W - 1);
+    }
+    dtr[3 * i] = dZ; dtr[3 * i + 1] = dY; dtr[3 * i + 2] = dX;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// smoothen_voxels3d: one zero-padded 1-D correlation along an axis of [B*D?, ...]   point_cloud_to.py:90-103
+//   element (o, i, r): outer index o, position i along the axis (length len, stride `inner`), inner index r
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_conv_axis(const float* __restrict__ in, float* __restrict__ out,
+                                                        size_t total, int len, int inner, TapsDyn taps) {
+  const int R = (taps.n - 1) / 2;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    const int i = (int)((e / inner) % len);
+    float acc = 0.f;
+    for (int k = 0; k < taps.n; ++k) {
+      const int p = i + k - R;
+      if (p >= 0 && p < len) acc = fmaf(taps.w[k], in[e + (ptrdiff_t)(k - R) * inner], acc);
+    }
+    out[e] = acc;
+  }
+}
+
+TapsDyn dyn_taps(const float* k, int n, bool flip) {
+  TapsDyn t;
+  t.n = n;
+  for (int i = 0; i < DPC_MAX_TAPS; ++i) t.w[i] = 0.f;
+  for (int i = 0; i < n; ++i) t.w[i] = k[flip ? n - 1 - i : i];
+  return t;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// DRC, general form                                       dpc/util/drc.py:48-129,145-160
+//   p_0 = e^eps y_0, p_k = y_k A_k (0<k<D), p_D = e^eps A_D, A_k = prod_{j<k} (1-y_j), y = clamp(v, eps, 1-eps)
+// ------------------------------------------------------------------------------------------------------
+__device__ inline float depth_psi(const DpcParams& P, int k) {
+  return k < P.D ? (float)((double)k / (double)P.D - 0.5 + (double)P.camera_distance) : P.max_depth;
+}
+
+__global__ __launch_bounds__(kThreads) void k_drc_fwd(DpcParams P, const float* __restrict__ vox,
+                                                      float* __restrict__ proj, float* __restrict__ probs,
+                                                      float* __restrict__ depth) {
+  const int HW = P.H * P.W, D = P.D;
+  const size_t rays = (size_t)P.B * HW;
+  const float eps = P.clip_val, hi = (float)(1.0 - (double)P.clip_val);
+  const double e_eps = exp((double)P.clip_val);
+  for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < rays; r += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = r / HW, pix = r - b * HW;
+    const float* col = vox + b * D * HW + pix;
+    double A = 1.0, sum = 0.0, dsum = 0.0;
+    for (int k = 0; k < D; ++k) {
+      const float y = fminf(fmaxf(col[(size_t)k * HW], eps), hi);
+      const double pk = (k == 0 ? e_eps : 1.0) * (double)y * A;
+      if (probs) probs[(size_t)k * rays + r] = (float)pk;
+      sum += pk;
+      dsum += pk * (double)depth_psi(P, k);
+      A *= 1.0 - (double)y;
+    }
+    const double pD = e_eps * A;
+    if (probs) probs[(size_t)D * rays + r] = (float)pD;
+    if (proj) proj[r] = (float)sum;
+    if (depth) depth[r] = (float)(dsum + pD * (double)P.max_depth);
+  }
+}
+
+// dL/dy_m = gp_m E_m A_m - (sum_{k>m} gp_k p_k) / (1 - y_m),  gp_k = dprobs_k + dproj [k<D] + ddepth psi_k.
+// Pass 1 parks the prefix products A_m in dvox (fp32), pass 2 walks the ray backwards with the suffix sum.
+__global__ __launch_bounds__(kThreads) void k_drc_bwd(DpcParams P, const float* __restrict__ vox,
+                                                      const float* __restrict__ dproj,
+                                                      const float* __restrict__ dprobs,
+                                                      const float* __restrict__ ddepth, float* __restrict__ dvox) {
+  const int HW = P.H * P.W, D = P.D;
+  const size_t rays = (size_t)P.B * HW;
+  const float eps = P.clip_val, hi = (float)(1.0 - (double)P.clip_val);
+  const double e_eps = exp((double)P.clip_val);
+  for (size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x; r < rays; r += (size_t)gridDim.x * blockDim.x) {
+    const size_t b = r / HW, pix = r - b * HW;
+    const float* col = vox + b * D * HW + pix;
+    float* dcol = dvox + b * D * HW + pix;
+    const double gproj = dproj ? (double)dproj[r] : 0.0;
+    const double gdepth = ddepth ? (double)ddepth[r] : 0.0;
+    double A = 1.0;
+    for (int k = 0; k < D; ++k) {
+      dcol[(size_t)k * HW] = (float)A;
+      A *= 1.0 - (double)fminf(fmaxf(col[(size_t)k * HW], eps), hi);
+    }
+    const double gD = (dprobs ? (double)dprobs[(size_t)D * rays + r] : 0.0) + gdepth * (double)P.max_depth;
+    double suffix = gD * e_eps * A;  // sum_{k>m} gp_k p_k
+    for (int m = D - 1; m >= 0; --m) {
+      const float v = col[(size_t)m * HW];
+      const float y = fminf(fmaxf(v, eps), hi);
+      const double Am = (double)dcol[(size_t)m * HW];
+      const double E = m == 0 ? e_eps : 1.0;
+      const double gp = (dprobs ? (double)dprobs[(size_t)m * rays + r] : 0.0) + gproj + gdepth * (double)depth_psi(P, m);
+      const double dy = gp * E * Am - suffix / (1.0 - (double)y);
+      dcol[(size_t)m * HW] = (v >= eps && v <= hi) ? (float)dy : 0.f;
+      suffix += gp * E * (double)y * Am;
+    }
+  }
+}
+
+int blocks_for(size_t n) { return (int)std::min<size_t>((n + kThreads - 1) / kThreads, 256 * 8); }
+
+}  // namespace
+
+extern "C" {
+
+int dpc_abi_version(void) { return DPC_ABI_VERSION; }
+
+const char* dpc_strerror(int code) {
+  switch (code) {
+    case DPC_OK: return "ok";
+    case DPC_ERR_NULL: return "a required pointer is NULL";
+    case DPC_ERR_SHAPE: return "B/N/D/H/W out of range";
+    case DPC_ERR_TAPS: return "smoothing kernel length must be odd and <= DPC_MAX_TAPS (fused path: effective radius <= 15)";
+    case DPC_ERR_LDS: return "an H x W plane does not fit the 160 KiB LDS tile";
+    case DPC_ERR_LAUNCH: return "HIP kernel launch failed";
+    case DPC_ERR_UNSUPPORTED: return "configuration is a dead branch of the reference";
+    default: return "unknown dpc error code";
+  }
+}
+
+int dpc_transform_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, float* out,
+                      void* stream) {
+  int rc = validate(p);
+  if (rc != DPC_OK) return rc;
+  if (p->B == 0 || p->N == 0) return DPC_OK;
+  if (!pc || !q || !out) return DPC_ERR_NULL;
+  dim3 grid(std::max(1, std::min((p->N + kThreads - 1) / kThreads, 64)), p->B);
+  hipLaunchKernelGGL(k_transform_fwd, grid, dim3(kThreads), 0, (hipStream_t)stream, *p, pc, q, t, f, out);
+  return launch_ok();
+}
+
+int dpc_transform_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                      const float* dout, float* dpc, float* dsmall, void* stream) {
+  int rc = validate(p);
+  if (rc != DPC_OK) return rc;
+  if (!pc || !q || !dout || !dpc || !dsmall) return DPC_ERR_NULL;
+  if (p->B == 0) return DPC_OK;
+  if (hipMemsetAsync(dsmall, 0, (size_t)p->B * DPC_SMALL_COLS * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return DPC_ERR_LAUNCH;
+  if (p->N == 0) return DPC_OK;
+  dim3 grid(std::max(1, std::min((p->N + kThreads - 1) / kThreads, 64)), p->B);
+  hipLaunchKernelGGL(k_transform_bwd, grid, dim3(kThreads), 0, (hipStream_t)stream, *p, pc, q, t, f, dout, dpc, dsmall);
+  return launch_ok();
+}
+
+int dpc_splat_bwd(const DpcParams* p, const void* tr, int tr_is_f64, const float* dvox, float* dtr, void* stream) {
+  int rc = validate(p);
+  if (rc != DPC_OK) return rc;
+  const size_t total = (size_t)p->B * p->N;
+  if (total == 0) return DPC_OK;
+  if (!tr || !dvox || !dtr) return DPC_ERR_NULL;
+  if (tr_is_f64)
+    hipLaunchKernelGGL(k_splat_bwd<double>, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream, *p,
+                       static_cast<const double*>(tr), dvox, dtr);
+  else
+    hipLaunchKernelGGL(k_splat_bwd<float>, dim3(blocks_for(total)), dim3(kThreads), 0, (hipStream_t)stream, *p,
+                       static_cast<const float*>(tr), dvox, dtr);
+  return launch_ok();
+}
+
+int dpc_smooth(const DpcParams* p, const float* host_kern_xy, const float* host_kern_z, int transpose, const float* in,
+               float* out, float* tmp, void* stream) {
+  int rc = validate(p);
+  if (rc != DPC_OK) return rc;
+  if (!in || !out || !tmp) return DPC_ERR_NULL;
+  if (p->taps_xy < 1 || p->taps_z < 1 || !host_kern_xy || !host_kern_z) return DPC_ERR_TAPS;
+  const size_t total = (size_t)p->B * p->D * p->H * p->W;
+  if (total == 0) return DPC_OK;
+  const bool flip = transpose != 0;
+  const TapsDyn kxy = dyn_taps(host_kern_xy, p->taps_xy, flip), kz = dyn_taps(host_kern_z, p->taps_z, flip);
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g(blocks_for(total)), blk(kThreads);
+  // reference order W, H, D (point_cloud_to.py:92-97); the adjoint runs D, H, W with flipped taps
+  if (!flip) {
+    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, in, out, total, p->W, 1, kxy);
+    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)out, tmp, total, p->H, p->W, kxy);
+    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)tmp, out, total, p->D, p->H * p->W, kz);
+  } else {
+    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, in, out, total, p->D, p->H * p->W, kz);
+    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)out, tmp, total, p->H, p->W, kxy);
+    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)tmp, out, total, p->W, 1, kxy);
+  }
+  return launch_ok();
+}
+
+int dpc_drc_fwd(const DpcParams* p, const float* vox, float* proj, float* probs, float* depth, void* stream) {
+  int rc = validate(p);
+  if (rc != DPC_OK) return rc;
+  if (!vox) return DPC_ERR_NULL;
+  const size_t rays = (size_t)p->B * p->H * p->W;
+  if (rays == 0) return DPC_OK;
+  hipLaunchKernelGGL(k_drc_fwd, dim3(blocks_for(rays)), dim3(kThreads), 0, (hipStream_t)stream, *p, vox, proj, probs,
+                     depth);
+  return launch_ok();
+}
+
+int dpc_drc_bwd(const DpcParams* p, const float* vox, const float* dproj, const float* dprobs, const float* ddepth,
+                float* dvox, void* stream) {
+  int rc = validate(p);
+  if (rc != DPC_OK) return rc;
+  if (!vox || !dvox) return DPC_ERR_NULL;
+  const size_t rays = (size_t)p->B * p->H * p->W;
+  if (rays == 0) return DPC_OK;
+  hipLaunchKernelGGL(k_drc_bwd, dim3(blocks_for(rays)), dim3(kThreads), 0, (hipStream_t)stream, *p, vox, dproj, dprobs,
+                     ddepth, dvox);
+  return launch_ok();
+}
+
+}  // extern "C"

@@ -1,0 +1,331 @@
+"""dpc.render -- MI355X-native differentiable point-cloud projection.
+
+Drop-in for the projection path of NiteshBharadwaj/pytorch-unsup-pc: the functions below keep the
+reference's names, argument order and defaults (reference file:line cited per function) and return tensors
+of the same shapes.  They are also importable under the names the reference's caller really uses
+(`util.point_cloud_to`, `util.drc`, `util.gauss_kernel`, `util.quaternion`) when this package's parent
+directory is on sys.path -- the same arrangement as the reference's dpc/run/startup.py.
+
+Differences from the reference, all deliberate (SURVEY.md section 8a "quirks"):
+  * fp32 tensors on the device of the INPUTS (the reference promotes to fp64 and picks the device globally);
+  * the Gaussian smoothing is applied (the reference's CUDA branch); `smooth=False` reproduces its CPU branch;
+  * dead branches of the reference raise NotImplementedError naming the config key;
+  * no `print` in the hot path; a point exactly on the +1/2 face contributes its in-range corners instead of
+    raising IndexError.
+"""
+import numpy as np
+import torch
+
+from . import _native
+from ._ops import Drc, Geometry, ProjectFused, Smooth, Splat, Transform
+
+__all__ = [
+    "pointcloud_project_fast", "pointcloud_project", "pc_perspective_transform", "pointcloud2voxels3d_fast",
+    "smoothen_voxels3d", "smooth_voxels3d", "smoothing_kernel", "gauss_kernel_1d", "separable_kernels",
+    "drc_projection", "drc_event_probabilities", "drc_depth_projection", "drc_depth_grid", "pc_point_dropout",
+    "quaternion_rotate", "quaternion_multiply", "quaternion_conjugate", "quaternion_normalise",
+    "get_smooth_sigma", "get_dropout_prob", "ProjectionOutputs",
+]
+
+
+# ------------------------------------------------------------------------------------------------------
+# config helpers (duck-typed cfg: any object with attribute access; fields of SURVEY.md section 5)
+# ------------------------------------------------------------------------------------------------------
+def _get(cfg, key, default):
+    try:
+        return getattr(cfg, key)
+    except (AttributeError, KeyError):
+        return default
+
+
+def _grid(cfg):
+    G = int(cfg.vox_size)
+    vz = int(_get(cfg, "vox_size_z", -1))
+    return (G if vz == -1 else vz), G, G
+
+
+def _check_live_branches(cfg):
+    if not _get(cfg, "pose_quaternion", True):
+        raise NotImplementedError("pose_quaternion: false is a broken branch of the reference "
+                                  "(dpc/util/point_cloud_to.py:153 UnboundLocalError)")
+    if _get(cfg, "ptn_max_projection", False):
+        raise NotImplementedError("ptn_max_projection: true returns a tuple in the reference (point_cloud_to.py:234)")
+    if not _get(cfg, "drc_logsum", True) or not _get(cfg, "drc_tf_cumulative", True):
+        raise NotImplementedError("drc_logsum: false / drc_tf_cumulative: false are dead branches of the reference "
+                                  "(dpc/util/drc.py:45,84-92)")
+
+
+def _geometry(cfg, kernel=None):
+    D, H, W = _grid(cfg)
+    kxy = kz = None
+    if kernel is not None:
+        kxy, kz = _kernel_taps(cfg, kernel)
+    return Geometry(D, H, W, kxy, kz, _get(cfg, "camera_distance", 2.0), _get(cfg, "focal_length", 1.875),
+                    _get(cfg, "drc_logsum_clip_val", 1e-5), _get(cfg, "max_depth", 10.0))
+
+
+def _kernel_taps(cfg, kernel):
+    """Host tap arrays (x/y, z) from what smoothing_kernel returns: a list of three 5-D kernels
+    [1,1,1,1,k], [1,1,1,k,1], [1,1,kz,1,1] applied in that order; a bare 1-D tensor is accepted too."""
+    if not _get(cfg, "pc_separable_gauss_filter", True):
+        raise NotImplementedError("pc_separable_gauss_filter: false leaves `kernel` unbound in the reference "
+                                  "(dpc/util/gauss_kernel.py:52-55)")
+    host = lambda k: np.ascontiguousarray(k.detach().cpu().numpy() if isinstance(k, torch.Tensor) else k,
+                                          dtype=np.float32).reshape(-1)
+    if isinstance(kernel, (list, tuple)):
+        if len(kernel) != 3:
+            raise ValueError("kernel must be the list of 3 separable kernels returned by smoothing_kernel")
+        kx, ky, kz = host(kernel[0]), host(kernel[1]), host(kernel[2])
+        if kx.shape != ky.shape or not np.array_equal(kx, ky):
+            raise NotImplementedError("different x and y kernels: smoothing_kernel never produces them")
+        return kx, kz
+    k = host(kernel)
+    return k, k
+
+
+# ------------------------------------------------------------------------------------------------------
+# Gaussian kernels                                   reference: dpc/util/gauss_kernel.py
+# ------------------------------------------------------------------------------------------------------
+def gauss_kernel_1d(l, sig):
+    """1-D Gaussian of side length l, fp32, normalised (dpc/util/gauss_kernel.py:5-11).  Host tensor: the
+    weights travel to the GPU as kernel arguments, not as a device tensor."""
+    x = torch.arange(float((-l) // 2) + 1.0, l // 2 + 1)
+    k = torch.exp(-x ** 2 / (2.0 * sig ** 2))
+    return k / k.sum()
+
+
+def separable_kernels(kernel):
+    """[1,1,1,1,k], [1,1,1,k,1], [1,1,k,1,1] views of a 1-D kernel (dpc/util/gauss_kernel.py:27-32)."""
+    n = kernel.shape[0]
+    return [kernel.reshape((1, 1, 1, 1, n)), kernel.reshape((1, 1, 1, n, 1)), kernel.reshape((1, 1, n, 1, 1))]
+
+
+def smoothing_kernel(cfg, sigma):
+    """The three separable kernels for pc_gauss_kernel_size and sigma (in voxels)
+    (dpc/util/gauss_kernel.py:35-55).  With vox_size_z != vox_size the z kernel has length
+    floor(fsz*ratio)|1 and sigma*ratio -- what the reference intends; its own reshape at :49 raises."""
+    fsz = int(cfg.pc_gauss_kernel_size)
+    k = gauss_kernel_1d(fsz, sigma)
+    vz = int(_get(cfg, "vox_size_z", -1))
+    if vz != -1:
+        ratio = vz / int(cfg.vox_size)
+        fz = int(np.floor(fsz * ratio))
+        if fz % 2 == 0:
+            fz += 1
+        kz = k if (fz == fsz and ratio == 1.0) else gauss_kernel_1d(fz, sigma * ratio)
+        return [k.reshape((1, 1, 1, 1, fsz)), k.reshape((1, 1, 1, fsz, 1)), kz.reshape((1, 1, fz, 1, 1))]
+    if not _get(cfg, "pc_separable_gauss_filter", True):
+        raise NotImplementedError("pc_separable_gauss_filter: false leaves `kernel` unbound in the reference "
+                                  "(dpc/util/gauss_kernel.py:52-55)")
+    return separable_kernels(k)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Quaternion helpers (host-side mirror; the fused kernels rotate in-register)   dpc/util/quaternion.py
+# ------------------------------------------------------------------------------------------------------
+def quaternion_multiply(a, b):
+    """Hamilton product, (w,x,y,z) order (dpc/util/quaternion.py:69-86); 3-vectors get a leading 0."""
+    pad = lambda v: torch.nn.functional.pad(v, (1, 0)) if v.shape[-1] == 3 else v
+    a, b = pad(a), pad(b)
+    if a.shape[-1] != 4 or b.shape[-1] != 4:
+        raise ValueError("Can't create a quaternion: the last dimension must be 3 or 4.")
+    aw, ax, ay, az = a.unbind(-1)
+    bw, bx, by, bz = b.unbind(-1)
+    return torch.stack((aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
+                        aw * by + ay * bw + az * bx - ax * bz, aw * bz + az * bw + ax * by - ay * bx), dim=-1)
+
+
+def quaternion_conjugate(q):
+    """[w, -x, -y, -z] (dpc/util/quaternion.py:89-92)."""
+    return q * torch.tensor([1.0, -1.0, -1.0, -1.0], dtype=q.dtype, device=q.device)
+
+
+def quaternion_normalise(q):
+    """q / |q| (dpc/util/quaternion.py:100-107)."""
+    return q / q.norm(p=2, dim=-1, keepdim=True)
+
+
+def quaternion_rotate(pc, q, inverse=False):
+    """Rotate [B,N,3] points by [B,4] quaternions, norm not detached (dpc/util/quaternion.py:110-132)."""
+    qn = quaternion_normalise(q).unsqueeze(1)
+    qc = quaternion_conjugate(qn)
+    w = quaternion_multiply(quaternion_multiply(qc, pc), qn) if inverse else quaternion_multiply(quaternion_multiply(qn, pc), qc)
+    return w[:, :, 1:4]
+
+
+# ------------------------------------------------------------------------------------------------------
+# Stage functions                                    reference: dpc/util/point_cloud_to.py, dpc/util/drc.py
+# ------------------------------------------------------------------------------------------------------
+def pc_perspective_transform(cfg, point_cloud, transform, predicted_translation=None, focal_length=None):
+    """[B,N,3] xyz -> [B,N,3] (z, y, x) camera-space coordinates (dpc/util/point_cloud_to.py:118-178)."""
+    _check_live_branches(cfg)
+    return Transform.apply(point_cloud, transform, predicted_translation, focal_length, _geometry(cfg))
+
+
+def pointcloud2voxels3d_fast(cfg, pc, rgb=None):
+    """Trilinear splat of transformed points into [B,D,H,W] (dpc/util/point_cloud_to.py:10-87).
+    Returns (voxels, None) like the reference."""
+    if rgb is not None:
+        raise NotImplementedError("rgb splatting is a dead branch of the reference (point_cloud_to.py:64 AttributeError)")
+    return Splat.apply(pc, _geometry(cfg)), None
+
+
+def smoothen_voxels3d(cfg, voxels, kernel):
+    """Separable zero-padded Gaussian over [B,1,D,H,W] in W,H,D order (dpc/util/point_cloud_to.py:90-103)."""
+    D, H, W = voxels.shape[-3:]
+    kxy, kz = _kernel_taps(cfg, kernel)
+    return Smooth.apply(voxels, Geometry(D, H, W, kxy, kz))
+
+
+smooth_voxels3d = smoothen_voxels3d
+
+
+def _drc_geometry(voxels, cfg):
+    B, D, H, W = voxels.shape[:4]
+    return Geometry(D, H, W, None, None, _get(cfg, "camera_distance", 2.0), _get(cfg, "focal_length", 1.875),
+                    _get(cfg, "drc_logsum_clip_val", 1e-5), _get(cfg, "max_depth", 10.0))
+
+
+def drc_event_probabilities(voxels, cfg):
+    """Ray-termination probabilities [D+1,B,H,W,1] of a [B,D,H,W,1] occupancy grid (dpc/util/drc.py:109-111)."""
+    _check_live_branches(cfg)
+    _, probs, _ = Drc.apply(voxels.squeeze(-1), _drc_geometry(voxels, cfg))
+    return probs.unsqueeze(-1)
+
+
+def drc_projection(voxels, cfg):
+    """(silhouette [B,H,W,1], probabilities [D+1,B,H,W,1]) (dpc/util/drc.py:114-129)."""
+    _check_live_branches(cfg)
+    proj, probs, _ = Drc.apply(voxels.squeeze(-1), _drc_geometry(voxels, cfg))
+    return proj.unsqueeze(-1), probs.unsqueeze(-1)
+
+
+def drc_depth_grid(cfg, z_size):
+    """psi_k = k/D - 1/2 + camera_distance, last = max_depth (dpc/util/drc.py:145-149)."""
+    i = torch.arange(0, z_size, 1, dtype=torch.float64)
+    return torch.cat([i / z_size - 0.5 + cfg.camera_distance, torch.tensor([cfg.max_depth], dtype=torch.float64)])
+
+
+def drc_depth_projection(p, cfg):
+    """Expected depth sum_k p_k psi_k of probabilities [D+1,B,H,W,1] (dpc/util/drc.py:152-160)."""
+    psi = drc_depth_grid(cfg, p.shape[0] - 1).to(device=p.device, dtype=p.dtype).reshape(-1, 1, 1, 1, 1)
+    return (p * psi).sum(0)
+
+
+# ------------------------------------------------------------------------------------------------------
+# The projection                                     reference: dpc/util/point_cloud_to.py:191-263
+# ------------------------------------------------------------------------------------------------------
+class ProjectionOutputs(dict):
+    """The reference's output dict.  `proj` (what the training loss consumes) comes from the fused kernels;
+    the other entries are produced on first access from the stage-level kernels, differentiably, so a step
+    that never reads them never pays for them."""
+
+    _LAZY = ("voxels", "tr_pc", "drc_probs", "proj_depth")
+
+    def __init__(self, proj, builder):
+        super().__init__(proj=proj, voxels_rgb=None, proj_rgb=None)
+        self._builder = builder
+        for k in self._LAZY:
+            dict.__setitem__(self, k, None)
+        self._pending = set(self._LAZY)
+
+    def _materialise(self, key):
+        if key in self._pending:
+            for k, v in self._builder().items():
+                if k in self._pending:
+                    dict.__setitem__(self, k, v)
+            self._pending.clear()
+
+    def __getitem__(self, key):
+        self._materialise(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self._materialise(key)
+        return dict.get(self, key, default)
+
+    def values(self):
+        self._materialise(next(iter(self._pending), None))
+        return dict.values(self)
+
+    def items(self):
+        self._materialise(next(iter(self._pending), None))
+        return dict.items(self)
+
+
+def _project_staged(cfg, geom, pc, q, t, f, s, smooth):
+    """The same chain composed from the stage-level kernels (all differentiable)."""
+    tr = Transform.apply(pc, q, t, f, geom)
+    raw = Splat.apply(tr, geom)
+    vox = torch.clamp(raw, 0.0, 1.0)
+    if smooth and geom.kxy is not None:
+        vox = Smooth.apply(vox, geom)
+    if s is not None:
+        vox = torch.clamp(vox * s.reshape(-1, 1, 1, 1).to(vox.dtype), 0.0, 1.0)
+    proj, probs, _ = Drc.apply(vox, geom)
+    probs = torch.flip(probs, [2]).unsqueeze(-1)
+    depth = drc_depth_projection(probs, cfg)
+    return {"proj": torch.flip(proj, [1]).unsqueeze(-1), "voxels": vox.unsqueeze(-1), "tr_pc": tr,
+            "drc_probs": probs, "proj_depth": depth}
+
+
+def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation, all_rgb, kernel=None,
+                            scaling_factor=None, focal_length=None, smooth=True):
+    """Project [B,N,3] point clouds to [B,H,W,1] silhouettes (dpc/util/point_cloud_to.py:191-263).
+
+    Same positional signature as the reference; returns a dict with the reference's keys
+    (proj, voxels, tr_pc, voxels_rgb, proj_rgb, drc_probs, proj_depth).  `smooth=False` reproduces the
+    reference's CPU branch, which skips the Gaussian (:210-212)."""
+    if all_rgb is not None:
+        raise NotImplementedError("all_rgb: the rgb branch of the reference is dead (point_cloud_to.py:64 AttributeError)")
+    _check_live_branches(cfg)
+    geom = _geometry(cfg, kernel if smooth else None)
+    staged = lambda: _project_staged(cfg, geom, point_cloud, transform, predicted_translation, focal_length,
+                                     scaling_factor, smooth)
+    try:
+        proj, _ = ProjectFused.apply(point_cloud, transform, predicted_translation, focal_length, scaling_factor, geom)
+    except _native.DpcError as e:
+        if e.code != _native.DPC_ERR_TAPS:
+            raise
+        # effective Gaussian radius > 15 voxels: beyond the fused kernels' register window; same math, staged
+        out = staged()
+        res = ProjectionOutputs(out["proj"], lambda: out)
+        return res
+    return ProjectionOutputs(proj, staged)
+
+
+pointcloud_project = pointcloud_project_fast
+
+
+def pc_point_dropout(points, rgb, keep_prob):
+    """Keep int(N*keep_prob) random points per cloud (dpc/util/point_cloud_to.py:269-295).  Same host RNG
+    protocol as the reference (one np.random.choice(N, n, replace=False) per cloud, in batch order), so a
+    seeded run selects the same points; the gather itself runs on the device."""
+    B, Npts = points.shape[0], points.shape[1]
+    n_out = int(Npts * keep_prob)
+    idx = np.stack([np.random.choice(Npts, n_out, replace=False) for _ in range(B)]).astype(np.int64)
+    idx_t = torch.from_numpy(idx).to(points.device)
+    rows = torch.arange(B, device=points.device).unsqueeze(1)
+    out_points = points[rows, idx_t]
+    out_rgb = rgb[rows, idx_t] if rgb is not None else None
+    return out_points, out_rgb
+
+
+# ------------------------------------------------------------------------------------------------------
+# Schedules read by the caller                       reference: dpc/models/model_pc_to.py:59-87
+# ------------------------------------------------------------------------------------------------------
+def get_smooth_sigma(cfg, global_step):
+    """sigma_rel(step), linear from pc_relative_sigma to pc_relative_sigma_end (model_pc_to.py:59-63)."""
+    return cfg.pc_relative_sigma + global_step / cfg.max_number_of_steps * (cfg.pc_relative_sigma_end - cfg.pc_relative_sigma)
+
+
+def get_dropout_prob(cfg, global_step):
+    """Point keep-probability schedule (model_pc_to.py:68-87)."""
+    if not cfg.pc_point_dropout_scheduled:
+        return cfg.pc_point_dropout
+    if cfg.pc_point_dropout_exponential_schedule:
+        raise NotImplementedError("pc_point_dropout_exponential_schedule: true calls torch.log on floats in the reference")
+    k0 = cfg.pc_point_dropout
+    slope = (1.0 - k0) / (cfg.pc_point_dropout_end_step - cfg.pc_point_dropout_start_step)
+    keep = slope * (global_step / cfg.max_number_of_steps) + (k0 - slope * cfg.pc_point_dropout_start_step)
+    return max(min(keep, 1.0), k0)

@@ -1,0 +1,272 @@
+"""torch.autograd.Function wrappers over the C ABI: tensors in, tensors out, hand-written backward.
+
+PyTorch is plumbing here (device memory, the current HIP stream, the autograd tape); every kernel is in
+csrc/.  All work is enqueued on torch's current stream without synchronising, so a whole
+forward+backward can be captured in a HIP graph.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+
+class Geometry:
+    """Per-call constants: grid, camera, tap weights (host side)."""
+
+    __slots__ = ("D", "H", "W", "kxy", "kz", "camera_distance", "focal_length", "clip_val", "max_depth")
+
+    def __init__(self, D, H, W, kxy=None, kz=None, camera_distance=2.0, focal_length=1.875, clip_val=1e-5,
+                 max_depth=10.0):
+        self.D, self.H, self.W = int(D), int(H), int(W)
+        self.kxy = None if kxy is None else np.ascontiguousarray(kxy, dtype=np.float32).reshape(-1)
+        self.kz = None if kz is None else np.ascontiguousarray(kz, dtype=np.float32).reshape(-1)
+        if (self.kxy is None) != (self.kz is None):
+            raise ValueError("give both the x/y and the z kernel, or neither")
+        for k in (self.kxy, self.kz):
+            if k is not None and (k.size % 2 == 0 or k.size > N.DPC_MAX_TAPS):
+                raise ValueError("smoothing kernels must have odd length <= %d, got %d" % (N.DPC_MAX_TAPS, k.size))
+        self.camera_distance, self.focal_length = float(camera_distance), float(focal_length)
+        self.clip_val, self.max_depth = float(clip_val), float(max_depth)
+
+    def params(self, B, Npts):
+        return N.DpcParams(int(B), int(Npts), self.D, self.H, self.W,
+                           0 if self.kxy is None else self.kxy.size, 0 if self.kz is None else self.kz.size,
+                           self.camera_distance, self.focal_length, self.clip_val, self.max_depth)
+
+    def kern_ptrs(self):
+        if self.kxy is None:
+            return None, None
+        return (self.kxy.ctypes.data_as(ctypes.c_void_p), self.kz.ctypes.data_as(ctypes.c_void_p))
+
+
+def _f32(t):
+    return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+def _meta(t):
+    """(dtype, shape) of an input -- kept on ctx instead of the tensor itself (no reference cycles)."""
+    return None if t is None else (t.dtype, tuple(t.shape))
+
+
+def _like_input(grad, meta):
+    """Gradients arrive in the input's dtype and shape, like autograd's would."""
+    return None if grad is None or meta is None else grad.to(meta[0]).reshape(meta[1])
+
+
+def locate_points(pc, q, t, f, geom):
+    """First launch of the fused forward alone: (tr_pc [B,N,3] fp32, cells [B,N,4] int32 point records)."""
+    dev = N.require_device(pc, q, t, f)
+    pc32, q32, t32, f32 = _f32(pc), _f32(q), _f32(t), _f32(f)
+    B, Npts = pc32.shape[0], pc32.shape[1]
+    P = geom.params(B, Npts)
+    tr = torch.empty_like(pc32)
+    cells = torch.empty((B, Npts, N.DPC_CELL_INTS), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        rc = N.lib().dpc_locate(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(tr), N.ptr(cells),
+                                N.stream_ptr(dev))
+    N.check(rc, "dpc_locate")
+    return tr, cells
+
+
+# ------------------------------------------------------------------------------------------------------
+# Fused hot path
+# ------------------------------------------------------------------------------------------------------
+class ProjectFused(torch.autograd.Function):
+    """pointcloud_project_fast as two launches forward, two backward (csrc/dpc_fused.hip).
+
+    forward(pc [B,N,3], q [B,4], t [B,3]|None, f [B,1]|None, s [B,1]|None, geom) -> proj [B,H,W,1]
+    ctx.smoothed ([B,D,H,W], pre-scale) is exposed for the lazily built `voxels` output.
+    """
+
+    @staticmethod
+    def forward(ctx, pc, q, t, f, s, geom):
+        dev = N.require_device(pc, q, t, f, s)
+        L = N.lib()
+        pc32, q32, t32, f32, s32 = _f32(pc), _f32(q), _f32(t), _f32(f), _f32(s)
+        B, Npts = pc32.shape[0], pc32.shape[1]
+        P = geom.params(B, Npts)
+        wpp = L.dpc_mask_words_per_plane(ctypes.byref(P))
+        smoothed = torch.empty((B, geom.D, geom.H, geom.W), dtype=torch.float32, device=dev)
+        mask = torch.empty((B, geom.D, wpp), dtype=torch.int64, device=dev)
+        cells = torch.empty((B, Npts, N.DPC_CELL_INTS), dtype=torch.int32, device=dev)
+        proj = torch.empty((B, geom.H, geom.W, 1), dtype=torch.float32, device=dev)
+        ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
+        kxy, kz = geom.kern_ptrs()
+        with torch.cuda.device(dev):
+            rc = L.dpc_project_fwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
+                                   None, N.ptr(cells), None, N.ptr(smoothed), N.ptr(mask), N.ptr(proj), N.ptr(ws),
+                                   N.stream_ptr(dev))
+        N.check(rc, "dpc_project_fwd")
+        ctx.geom = geom
+        ctx.inputs = tuple(_meta(x) for x in (pc, q, t, f, s))
+        ctx.save_for_backward(pc32, q32, t32 if t32 is not None else pc32.new_empty(0),
+                              f32 if f32 is not None else pc32.new_empty(0),
+                              s32 if s32 is not None else pc32.new_empty(0), smoothed, mask, cells)
+        ctx.has = (t is not None, f is not None, s is not None)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(smoothed)
+        return proj, smoothed
+
+    @staticmethod
+    def backward(ctx, dproj, _dsmoothed):
+        if dproj is None:
+            return None, None, None, None, None, None
+        pc32, q32, t32, f32, s32, smoothed, mask, cells = ctx.saved_tensors
+        has_t, has_f, has_s = ctx.has
+        t32 = t32 if has_t else None
+        f32 = f32 if has_f else None
+        s32 = s32 if has_s else None
+        geom = ctx.geom
+        dev = pc32.device
+        L = N.lib()
+        B, Npts = pc32.shape[0], pc32.shape[1]
+        P = geom.params(B, Npts)
+        dproj32 = dproj.detach().to(torch.float32).contiguous()
+        dpc = torch.empty_like(pc32)
+        dsmall = torch.empty((B, N.DPC_SMALL_COLS), dtype=torch.float32, device=dev)
+        ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
+        kxy, kz = geom.kern_ptrs()
+        with torch.cuda.device(dev):
+            rc = L.dpc_project_bwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
+                                   N.ptr(cells), N.ptr(smoothed), N.ptr(mask), N.ptr(dproj32), N.ptr(dpc), N.ptr(dsmall),
+                                   N.ptr(ws), N.stream_ptr(dev))
+        N.check(rc, "dpc_project_bwd")
+        pc, q, t, f, s = ctx.inputs
+        return (_like_input(dpc, pc), _like_input(dsmall[:, N.COL_DQ:N.COL_DQ + 4], q),
+                _like_input(dsmall[:, N.COL_DT:N.COL_DT + 3], t) if has_t else None,
+                _like_input(dsmall[:, N.COL_DF:N.COL_DF + 1], f) if has_f else None,
+                _like_input(dsmall[:, N.COL_DS:N.COL_DS + 1], s) if has_s else None, None)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Stage-level functions (one per reference function)
+# ------------------------------------------------------------------------------------------------------
+class Transform(torch.autograd.Function):
+    """pc_perspective_transform, quaternion branch."""
+
+    @staticmethod
+    def forward(ctx, pc, q, t, f, geom):
+        dev = N.require_device(pc, q, t, f)
+        pc32, q32, t32, f32 = _f32(pc), _f32(q), _f32(t), _f32(f)
+        P = geom.params(pc32.shape[0], pc32.shape[1])
+        out = torch.empty_like(pc32)
+        with torch.cuda.device(dev):
+            rc = N.lib().dpc_transform_fwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(out),
+                                           N.stream_ptr(dev))
+        N.check(rc, "dpc_transform_fwd")
+        ctx.geom, ctx.inputs, ctx.saved = geom, tuple(_meta(x) for x in (pc, q, t, f)), (pc32, q32, t32, f32)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        pc32, q32, t32, f32 = ctx.saved
+        dev = pc32.device
+        P = ctx.geom.params(pc32.shape[0], pc32.shape[1])
+        dout32 = dout.detach().to(torch.float32).contiguous()
+        dpc = torch.empty_like(pc32)
+        dsmall = torch.empty((pc32.shape[0], N.DPC_SMALL_COLS), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = N.lib().dpc_transform_bwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32),
+                                           N.ptr(dout32), N.ptr(dpc), N.ptr(dsmall), N.stream_ptr(dev))
+        N.check(rc, "dpc_transform_bwd")
+        pc, q, t, f = ctx.inputs
+        return (_like_input(dpc, pc), _like_input(dsmall[:, N.COL_DQ:N.COL_DQ + 4], q),
+                _like_input(dsmall[:, N.COL_DT:N.COL_DT + 3], t), _like_input(dsmall[:, N.COL_DF:N.COL_DF + 1], f), None)
+
+
+class Splat(torch.autograd.Function):
+    """pointcloud2voxels3d_fast: tr [B,N,3] (z,y,x) -> voxels [B,D,H,W]."""
+
+    @staticmethod
+    def forward(ctx, tr, geom):
+        dev = N.require_device(tr)
+        is64 = tr.dtype == torch.float64  # the reference's direct callers pass fp64 coordinates; keep them
+        trc = tr.detach().contiguous() if is64 else _f32(tr)
+        P = geom.params(trc.shape[0], trc.shape[1])
+        vox = torch.empty((trc.shape[0], geom.D, geom.H, geom.W), dtype=torch.float32, device=dev)
+        cells = torch.empty((trc.shape[0], trc.shape[1], N.DPC_CELL_INTS), dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = N.lib().dpc_splat_fwd(ctypes.byref(P), N.ptr(trc), int(is64), N.ptr(cells), N.ptr(vox), N.stream_ptr(dev))
+        N.check(rc, "dpc_splat_fwd")
+        ctx.geom, ctx.tr, ctx.trc, ctx.is64 = geom, _meta(tr), trc, is64
+        return vox
+
+    @staticmethod
+    def backward(ctx, dvox):
+        trc = ctx.trc
+        dev = trc.device
+        P = ctx.geom.params(trc.shape[0], trc.shape[1])
+        dvox32 = dvox.detach().to(torch.float32).contiguous()
+        dtr = torch.empty(trc.shape, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = N.lib().dpc_splat_bwd(ctypes.byref(P), N.ptr(trc), int(ctx.is64), N.ptr(dvox32), N.ptr(dtr),
+                                       N.stream_ptr(dev))
+        N.check(rc, "dpc_splat_bwd")
+        return _like_input(dtr, ctx.tr), None
+
+
+def _smooth_call(x32, geom, transpose):
+    dev = x32.device
+    B = x32.shape[0]
+    P = geom.params(B, 0)
+    out, tmp = torch.empty_like(x32), torch.empty_like(x32)
+    kxy, kz = geom.kern_ptrs()
+    with torch.cuda.device(dev):
+        rc = N.lib().dpc_smooth(ctypes.byref(P), kxy, kz, int(transpose), N.ptr(x32), N.ptr(out), N.ptr(tmp),
+                                N.stream_ptr(dev))
+    N.check(rc, "dpc_smooth")
+    return out
+
+
+class Smooth(torch.autograd.Function):
+    """smoothen_voxels3d on a [B,D,H,W] (or [B,1,D,H,W]) grid; the backward is the adjoint correlation."""
+
+    @staticmethod
+    def forward(ctx, vox, geom):
+        N.require_device(vox)
+        ctx.geom, ctx.vox = geom, _meta(vox)
+        return _smooth_call(_f32(vox).reshape(-1, geom.D, geom.H, geom.W), geom, False).reshape(vox.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        geom = ctx.geom
+        d32 = dout.detach().to(torch.float32).contiguous().reshape(-1, geom.D, geom.H, geom.W)
+        return _like_input(_smooth_call(d32, geom, True), ctx.vox), None
+
+
+class Drc(torch.autograd.Function):
+    """drc_projection + drc_depth_projection: vox [B,D,H,W] -> proj [B,H,W], probs [D+1,B,H,W], depth [B,H,W]
+    (no flips; the caller applies the reference's flips)."""
+
+    @staticmethod
+    def forward(ctx, vox, geom):
+        dev = N.require_device(vox)
+        vox32 = _f32(vox)
+        B = vox32.shape[0]
+        P = geom.params(B, 0)
+        proj = torch.empty((B, geom.H, geom.W), dtype=torch.float32, device=dev)
+        probs = torch.empty((geom.D + 1, B, geom.H, geom.W), dtype=torch.float32, device=dev)
+        depth = torch.empty((B, geom.H, geom.W), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = N.lib().dpc_drc_fwd(ctypes.byref(P), N.ptr(vox32), N.ptr(proj), N.ptr(probs), N.ptr(depth),
+                                     N.stream_ptr(dev))
+        N.check(rc, "dpc_drc_fwd")
+        ctx.geom, ctx.vox, ctx.vox32 = geom, _meta(vox), vox32
+        ctx.set_materialize_grads(False)  # unused outputs arrive as None, not as zero-filled [D+1,B,H,W] tensors
+        return proj, probs, depth
+
+    @staticmethod
+    def backward(ctx, dproj, dprobs, ddepth):
+        vox32 = ctx.vox32
+        dev = vox32.device
+        P = ctx.geom.params(vox32.shape[0], 0)
+        c = lambda g: None if g is None else g.detach().to(torch.float32).contiguous()
+        dproj, dprobs, ddepth = c(dproj), c(dprobs), c(ddepth)
+        dvox = torch.empty_like(vox32)
+        with torch.cuda.device(dev):
+            rc = N.lib().dpc_drc_bwd(ctypes.byref(P), N.ptr(vox32), N.ptr(dproj), N.ptr(dprobs), N.ptr(ddepth),
+                                     N.ptr(dvox), N.stream_ptr(dev))
+        N.check(rc, "dpc_drc_bwd")
+        return _like_input(dvox, ctx.vox), None
