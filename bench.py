@@ -1,0 +1,218 @@
+#!/usr/bin/env python3
+"""Benchmark of the differentiable point-cloud projection hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of synthetic clouds already resident in HBM:
+pointcloud_project_fast (transform -> splat -> clamp -> Gaussian -> scale/clamp -> DRC silhouette), the loss
+sum((proj-gt)^2)/B, and the hand-written backward to d(pc), d(q), d(s).  Workload = BASELINE.json configs[1]
+(SURVEY.md 8(d) "c2"): B=32 clouds, N=8000 points, 64^3 grid, 21-tap Gaussian, sigma = 0.01 world units
+(sigma_rel 0.64).  The step is captured once into a HIP graph and replayed; weak scaling (every rank runs
+its own B=32 shard, no data-path collective; the per-step losses are all-reduced once after the timed loop).
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (per-kernel HIP-event timing from
+the library's opt-in profiler, eager pass after the timed region); `roofline_step` prices the whole step with
+the contractual algorithmic bytes A(N,G) of SURVEY.md 8(d); `cpu_baseline` times the CPU oracle (a port of the
+reference's PyTorch CPU path) on a bounded sample on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "pytorch-unsup-pc_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch
+import torch.distributed as dist
+
+B, N_PTS, G, KSIZE, SIGMA_REL = 32, 8000, 64, 21, 0.64
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def algorithmic_bytes_per_cloud(n, g):
+    """A(N,G) = 36N + min(32N, 4G^3) + 36G^3 + 8G^2 (fwd+bwd, fp32)."""
+    return 36 * n + min(32 * n, 4 * g ** 3) + 36 * g ** 3 + 8 * g ** 2
+
+
+def kernel_bytes_per_cloud(n, g):
+    """Bytes each launch of THIS implementation must move per cloud (kernel table)."""
+    g3, g2 = g ** 3, g ** 2
+    return {
+        "k_locate": 12 * n + 16 * n,                    # read pc, write point records
+        "k_splat_hw": 16 * n + 4 * g3 + g3 // 8,        # read records, write T (after W/H passes) + clamp mask
+        "k_zcol_fwd": 4 * g3 + 4 * g3 + 4 * g2,         # read T, write smoothed grid, write silhouette
+        "k_zcol_bwd": 4 * g3 + 4 * g2 + 4 * g3,         # read smoothed grid + dproj, write dT
+        "k_gather_hw": 4 * g3 + g3 // 8 + 16 * n + 24 * n,  # read dT + mask + records + pc, write dpc
+    }
+
+
+def make_inputs(device, seed):
+    from oracle.dpc_oracle import synth_inputs  # input generator only (shared with the tests)
+
+    pc, q, s, gt, _, _ = synth_inputs(B, N_PTS, G, seed)
+    return [x.to(device=device, dtype=torch.float32) for x in (pc, q, s, gt)]
+
+
+def cpu_baseline():
+    """Oracle (op-for-op torch-CPU fp64 port of the reference path, with the Gaussian) fwd+bwd on a bounded
+    sample of the same workload: 4 of the 32 clouds, best of 3."""
+    from oracle import dpc_oracle as O
+
+    nb = 4
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=KSIZE)
+    pc, q, s, gt, _, _ = O.synth_inputs(B, N_PTS, G, 1234)
+    pc, q, s, gt = pc[:nb], q[:nb], s[:nb], gt[:nb]
+    kern = O.smoothing_kernel(cfg, SIGMA_REL)
+    best = float("inf")
+    for _ in range(3):
+        a, b_, c = (x.clone().requires_grad_(True) for x in (pc, q, s))
+        t0 = time.perf_counter()
+        out = O.pointcloud_project_fast(cfg, a, b_, None, None, kern, scaling_factor=c)
+        (((out["proj"] - gt) ** 2).sum() / nb).backward()
+        best = min(best, time.perf_counter() - t0)
+    return {"value": nb / best, "unit": "point-clouds/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d of the %d clouds of the workload, fwd+bwd with Gaussian (reference CUDA-branch semantics), "
+                      "fp64, best of 3" % (nb, B)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP graph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path in dpc.render)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+
+    import dpc.render as R
+    from dpc.render import _native
+    from oracle.dpc_oracle import Cfg
+
+    cfg = Cfg(vox_size=G, pc_gauss_kernel_size=KSIZE)
+    kern = R.smoothing_kernel(cfg, SIGMA_REL)
+    pc, q, s, gt = make_inputs(device, 1234 + rank)
+    pc.requires_grad_(True), q.requires_grad_(True), s.requires_grad_(True)
+
+    def step():
+        pc.grad = q.grad = s.grad = None
+        proj = R.pointcloud_project_fast(cfg, pc, q, None, None, kern, scaling_factor=s)["proj"]
+        loss = ((proj - gt) ** 2).sum() / B
+        loss.backward()
+        return loss
+
+    side = torch.cuda.Stream(device)
+    graph = None
+    with torch.cuda.stream(side):
+        for _ in range(3):  # settle allocator / lazy init before capture
+            step()
+        side.synchronize()
+        if not args.no_graph:
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                static_loss = step()
+
+        last = [static_loss if graph is not None else None]
+
+        def run_step(i):
+            if graph is not None:
+                graph.replay()
+            else:
+                last[0] = step()
+
+        for i in range(args.warmup):
+            run_step(i)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(side)
+        for i in range(args.steps):
+            run_step(i)
+        ev1.record(side)
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        wall = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)
+
+        tt = torch.tensor([wall], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        loss_t = last[0].detach().clone().reshape(1) if last[0] is not None else torch.zeros(1, device=device)
+        if world > 1:
+            dist.all_reduce(loss_t, op=dist.ReduceOp.SUM)  # the only exchange: the final step's loss, once
+        wall = tt.item()
+
+        # per-kernel durations (eager pass, library's event profiler) -> dominant kernel
+        kern_ms = {}
+        if rank == 0:
+            prof = _native.profile_kernels(lambda: [step() for _ in range(30)], device)
+            kern_ms = {k: sum(v[len(v) // 3:]) / len(v[len(v) // 3:]) for k, v in prof.items()}
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    clouds_per_s = world * B * args.steps / wall
+    ms_per_step = 1e3 * wall / args.steps
+    a_bytes = algorithmic_bytes_per_cloud(N_PTS, G)
+    kb = kernel_bytes_per_cloud(N_PTS, G)
+    dom = max(kern_ms, key=kern_ms.get) if kern_ms else None
+    roofline = None
+    if dom is not None:
+        ach = B * kb[dom] / (kern_ms[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": 1e3 * kern_ms[dom],
+                    "algorithmic_bytes_per_launch": B * kb[dom]}
+    step_ach = (B * a_bytes) / (dev_ms * 1e-3 / args.steps) / 1e9
+    out = {
+        "metric": "point-clouds/sec (8000 pts->64^3->128^2 proj) fwd+bwd", "value": clouds_per_s,
+        "unit": "point-clouds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1] (c2): B=32 clouds x 8000 pts -> 64^3 grid, 21-tap Gaussian "
+                               "sigma_rel=0.64 (sigma=0.01), DRC silhouette 64x64 vs mean-pooled 128x128 mask, "
+                               "loss sum((proj-gt)^2)/B, backward to pc, q, s",
+                   "clouds_per_gpu": B, "points": N_PTS, "grid": G, "taps": KSIZE, "sigma_rel": SIGMA_REL,
+                   "launch": "eager" if graph is None else "hip-graph replay", "sharding": "clouds, no collective"},
+        "roofline": roofline,
+        "roofline_step": {"bound": "hbm", "achieved": step_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": step_ach / HBM_PEAK_GBS, "algorithmic_bytes_per_cloud": a_bytes,
+                          "device_ms_per_step": dev_ms / args.steps,
+                          "note": "whole fwd+bwd step on rank 0 (HIP events on the launch stream) priced with A(N,G) of SURVEY 8(d)"},
+        "kernels_us": {k: 1e3 * v for k, v in sorted(kern_ms.items())},
+        "kernels_gbs": {k: B * kb[k] / (v * 1e-3) / 1e9 for k, v in sorted(kern_ms.items()) if k in kb},
+        "loss_mean": float(loss_t.item() / world),
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

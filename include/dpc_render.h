@@ -144,6 +144,17 @@ int dpc_drc_fwd(const DpcParams* p, const float* vox, float* proj, float* probs,
 int dpc_drc_bwd(const DpcParams* p, const float* vox, const float* dproj, const float* dprobs,
                 const float* ddepth, float* dvox, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Opt-in measurement aid (nothing in the reference corresponds to it).  After dpc_profile_enable(capacity)
+ * every launch of the fused path is bracketed by hipEvents on its stream; synchronise the stream, then read
+ * dpc_profile_count() entries with dpc_profile_get(i, &kernel_name, &milliseconds).  Off by default; the only
+ * global state in the library; not usable while a hipGraph is being captured.
+ * ------------------------------------------------------------------------------------------------- */
+int dpc_profile_enable(int capacity);
+int dpc_profile_disable(void);
+int dpc_profile_count(void);
+int dpc_profile_get(int i, const char** name, float* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include "dpc_common.h"
+#include "dpc_profile.h"
 
 namespace {
 
@@ -700,8 +701,8 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
   PointRec* recs = reinterpret_cast<PointRec*>(cells);
 
   if (p->N > 0) {
-    hipLaunchKernelGGL(k_locate<0>, dim3((p->N + 255) / 256, p->B), dim3(256), 0, st, *p, (const void*)pc, q, t, f, tr_pc,
-                       recs);
+    DPC_LAUNCH("k_locate", k_locate<0>, dim3((p->N + 255) / 256, p->B), dim3(256), 0, st, *p, (const void*)pc, q, t, f,
+               tr_pc, recs);
     if ((rc = launch_ok()) != DPC_OK) return rc;
   }
 
@@ -710,8 +711,8 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
   {                                                                                                             \
     auto kern = k_splat_hw<RB>;                                                                                 \
     if ((rc = set_lds(kern, lds)) == DPC_OK)                                                                    \
-      hipLaunchKernelGGL(kern, gslab, dim3(slab_threads(p)), lds, st, *p, (const PointRec*)recs,                \
-                         make_taps<RB>(host_kern_xy, pxy, false), Zs, raw, Tbuf, mask);                         \
+      DPC_LAUNCH("k_splat_hw", kern, gslab, dim3(slab_threads(p)), lds, st, *p, (const PointRec*)recs,          \
+                 make_taps<RB>(host_kern_xy, pxy, false), Zs, raw, Tbuf, mask);                                 \
   }
   DPC_FOR_BUCKET(pxy.bucket, LAUNCH_SPLAT)
 #undef LAUNCH_SPLAT
@@ -724,15 +725,15 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
 #define LAUNCH_ZFWD(RB)                                                                                          \
   {                                                                                                              \
     const TapsT<RB> tz = make_taps<RB>(host_kern_z, pz, false);                                                  \
-    if (p->D == 32) { hipLaunchKernelGGL((k_zcol_fwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj); done = true; } \
-    else if (p->D == 64) { hipLaunchKernelGGL((k_zcol_fwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj); done = true; } \
-    else if (p->D == 128) { hipLaunchKernelGGL((k_zcol_fwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj); done = true; } \
+    if (p->D == 32) { DPC_LAUNCH("k_zcol_fwd", (k_zcol_fwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj); done = true; } \
+    else if (p->D == 64) { DPC_LAUNCH("k_zcol_fwd", (k_zcol_fwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj); done = true; } \
+    else if (p->D == 128) { DPC_LAUNCH("k_zcol_fwd", (k_zcol_fwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj); done = true; } \
   }
   if (pz.bucket >= 0) { DPC_FOR_BUCKET(pz.bucket, LAUNCH_ZFWD) }
 #undef LAUNCH_ZFWD
   if (!done) {
     rc = DPC_OK;
-    hipLaunchKernelGGL(k_zcol_fwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s,
+    DPC_LAUNCH("k_zcol_fwd", k_zcol_fwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s,
                        make_taps_dyn(host_kern_z, p->taps_z, false), smoothed, proj);
   }
   return launch_ok();
@@ -766,15 +767,15 @@ int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const f
 #define LAUNCH_ZBWD(RB)                                                                                           \
   {                                                                                                               \
     const TapsT<RB> tz = make_taps<RB>(host_kern_z, pz, true);                                                    \
-    if (p->D == 32) { hipLaunchKernelGGL((k_zcol_bwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, tz, dT, ds_part, dsmall); done = true; } \
-    else if (p->D == 64) { hipLaunchKernelGGL((k_zcol_bwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, tz, dT, ds_part, dsmall); done = true; } \
-    else if (p->D == 128) { hipLaunchKernelGGL((k_zcol_bwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, tz, dT, ds_part, dsmall); done = true; } \
+    if (p->D == 32) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, tz, dT, ds_part, dsmall); done = true; } \
+    else if (p->D == 64) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, tz, dT, ds_part, dsmall); done = true; } \
+    else if (p->D == 128) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, tz, dT, ds_part, dsmall); done = true; } \
   }
   if (pz.bucket >= 0) { DPC_FOR_BUCKET(pz.bucket, LAUNCH_ZBWD) }
 #undef LAUNCH_ZBWD
   if (!done) {
     rc = DPC_OK;
-    hipLaunchKernelGGL(k_zcol_bwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj,
+    DPC_LAUNCH("k_zcol_bwd", k_zcol_bwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj,
                        make_taps_dyn(host_kern_z, p->taps_z, true), dT, ds_part, dsmall);
   }
   if ((rc = launch_ok()) != DPC_OK) return rc;
@@ -784,7 +785,7 @@ int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const f
   {                                                                                                              \
     auto kern = k_gather_hw<RB>;                                                                                 \
     if ((rc = set_lds(kern, lds)) == DPC_OK)                                                                     \
-      hipLaunchKernelGGL(kern, gslab, dim3(slab_threads(p)), lds, st, *p, reinterpret_cast<const PointRec*>(cells), \
+      DPC_LAUNCH("k_gather_hw", kern, gslab, dim3(slab_threads(p)), lds, st, *p, reinterpret_cast<const PointRec*>(cells), \
                          pc, q, t, f, make_taps<RB>(host_kern_xy, pxy, true), Zs, dT, mask, ds_part, ntile, dpc,    \
                          dsmall);                                                                                \
   }

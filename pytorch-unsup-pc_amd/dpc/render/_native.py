@@ -25,6 +25,7 @@ SYMBOLS = (
     "dpc_abi_version", "dpc_strerror", "dpc_mask_words_per_plane", "dpc_workspace_bytes", "dpc_locate",
     "dpc_project_fwd", "dpc_project_bwd", "dpc_transform_fwd", "dpc_transform_bwd",
     "dpc_splat_fwd", "dpc_splat_bwd", "dpc_smooth", "dpc_drc_fwd", "dpc_drc_bwd",
+    "dpc_profile_enable", "dpc_profile_disable", "dpc_profile_count", "dpc_profile_get",
 )
 
 
@@ -71,6 +72,12 @@ def lib():
         L.dpc_splat_fwd.argtypes = [pp, vp, ctypes.c_int, vp, vp, vp]
         L.dpc_splat_bwd.restype = ctypes.c_int
         L.dpc_splat_bwd.argtypes = [pp, vp, ctypes.c_int, vp, vp, vp]
+        L.dpc_profile_enable.restype = ctypes.c_int
+        L.dpc_profile_enable.argtypes = [ctypes.c_int]
+        L.dpc_profile_disable.restype = ctypes.c_int
+        L.dpc_profile_count.restype = ctypes.c_int
+        L.dpc_profile_get.restype = ctypes.c_int
+        L.dpc_profile_get.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float)]
         L.dpc_smooth.restype = ctypes.c_int
         L.dpc_smooth.argtypes = [pp, vp, vp, ctypes.c_int, vp, vp, vp, vp]
         if L.dpc_abi_version() != ABI_VERSION:
@@ -119,3 +126,20 @@ def require_device(*tensors):
         elif t.device != dev:
             raise RuntimeError("dpc.render: tensors on different devices (%s vs %s)" % (dev, t.device))
     return dev
+
+
+def profile_kernels(fn, device, capacity=4096):
+    """Run fn() with the library's per-kernel event timing on; returns {kernel_name: [ms, ...]}."""
+    L = lib()
+    check(L.dpc_profile_enable(capacity), "dpc_profile_enable")
+    try:
+        fn()
+        torch.cuda.synchronize(device)
+    finally:
+        L.dpc_profile_disable()
+    out = {}
+    name, ms = ctypes.c_char_p(), ctypes.c_float()
+    for i in range(L.dpc_profile_count()):
+        check(L.dpc_profile_get(i, ctypes.byref(name), ctypes.byref(ms)), "dpc_profile_get")
+        out.setdefault(name.value.decode(), []).append(ms.value)
+    return out
