@@ -115,7 +115,7 @@ def main():
     def step():
         pc.grad = q.grad = s.grad = None
         proj = R.pointcloud_project_fast(cfg, pc, q, None, None, kern, scaling_factor=s)["proj"]
-        loss = ((proj - gt) ** 2).sum() / B
+        loss, _ = R.silhouette_loss(proj, gt)  # sum((proj-gt)^2)/B fused with its gradient
         loss.backward()
         return loss
 

@@ -144,6 +144,15 @@ int dpc_drc_fwd(const DpcParams* p, const float* vox, float* proj, float* probs,
 int dpc_drc_bwd(const DpcParams* p, const float* vox, const float* dproj, const float* dprobs,
                 const float* ddepth, float* dvox, void* stream);
 
+/* Caller-side silhouette loss fused with its gradient: add_proj_loss /
+ * proj_loss_pose_candidates (dpc/models/model_pc_to.py:339-385, 410-440).  gt [S, n_pix] is the ground-truth
+ * mask already pooled to the silhouette size, pred [S*K, n_pix] the K candidate silhouettes per sample.
+ * Per sample the candidate with the smallest sum of squared differences wins (first minimum, like
+ * torch.argmin); loss = sum over winners (gt-pred)^2 / S.  Outputs: loss_part [S] (sum them for the loss),
+ * winner [S], dpred [S*K, n_pix] = d loss / d pred (zero for losing candidates). */
+int dpc_silhouette_loss(const float* gt, const float* pred, int S, int K, int n_pix, float* loss_part, int32_t* winner,
+                        float* dpred, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Opt-in measurement aid (nothing in the reference corresponds to it).  After dpc_profile_enable(capacity)
  * every launch of the fused path is bracketed by hipEvents on its stream; synchronise the stream, then read

@@ -207,6 +207,55 @@ __global__ __launch_bounds__(kThreads) void k_drc_bwd(DpcParams P, const float* 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Silhouette loss of the caller (dpc/models/model_pc_to.py:339-385,410-440), fused with its gradient:
+//   K == 1: loss = sum (gt - pred)^2 / S
+//   K  > 1: per sample pick the candidate with the smallest sum of squared differences (argmin over K),
+//           loss = sum over winners (gt - pred)^2 / S; losing candidates get zero gradient.
+// gt [S, n_pix] (already pooled to the silhouette size), pred [S*K, n_pix].  One block per sample.
+//   out: loss_part [S] (this sample's winning sum / S), winner [S] (int32), dpred [S*K, n_pix] (d loss / d pred)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kThreads) void k_silhouette_loss(const float* __restrict__ gt, const float* __restrict__ pred,
+                                                              int K, int n_pix, float inv_S,
+                                                              float* __restrict__ loss_part, int* __restrict__ winner,
+                                                              float* __restrict__ dpred) {
+  __shared__ float red[kThreads / DPC_WAVE];
+  __shared__ float best_val;
+  __shared__ int best_k;
+  const int smp = blockIdx.x;
+  const float* g = gt + (size_t)smp * n_pix;
+  if (threadIdx.x == 0) { best_val = 0.f; best_k = 0; }
+  for (int k = 0; k < K; ++k) {
+    const float* p = pred + ((size_t)smp * K + k) * n_pix;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n_pix; i += blockDim.x) {
+      const float d = g[i] - p[i];
+      acc = fmaf(d, d, acc);
+    }
+    acc = wave_sum(acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tot = 0.f;
+      for (int w = 0; w < (int)(blockDim.x / DPC_WAVE); ++w) tot += red[w];
+      if (k == 0 || tot < best_val) { best_val = tot; best_k = k; }  // first minimum wins, like torch.argmin
+    }
+  }
+  __syncthreads();
+  const int win = best_k;
+  if (threadIdx.x == 0) {
+    loss_part[smp] = best_val * inv_S;
+    winner[smp] = win;
+  }
+  for (int k = 0; k < K; ++k) {
+    const float* p = pred + ((size_t)smp * K + k) * n_pix;
+    float* d = dpred + ((size_t)smp * K + k) * n_pix;
+    const float scale = k == win ? 2.f * inv_S : 0.f;
+    for (int i = threadIdx.x; i < n_pix; i += blockDim.x) d[i] = scale * (p[i] - g[i]);
+  }
+}
+
 int blocks_for(size_t n) { return (int)std::min<size_t>((n + kThreads - 1) / kThreads, 256 * 8); }
 
 }  // namespace
@@ -290,6 +339,16 @@ int dpc_smooth(const DpcParams* p, const float* host_kern_xy, const float* host_
     hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)out, tmp, total, p->H, p->W, kxy);
     hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)tmp, out, total, p->W, 1, kxy);
   }
+  return launch_ok();
+}
+
+int dpc_silhouette_loss(const float* gt, const float* pred, int S, int K, int n_pix, float* loss_part, int32_t* winner,
+                        float* dpred, void* stream) {
+  if (S < 0 || K < 1 || n_pix < 1) return DPC_ERR_SHAPE;
+  if (S == 0) return DPC_OK;
+  if (!gt || !pred || !loss_part || !winner || !dpred) return DPC_ERR_NULL;
+  hipLaunchKernelGGL(k_silhouette_loss, dim3(S), dim3(kThreads), 0, (hipStream_t)stream, gt, pred, K, n_pix,
+                     1.0f / (float)S, loss_part, winner, dpred);
   return launch_ok();
 }
 

@@ -17,14 +17,14 @@ import numpy as np
 import torch
 
 from . import _native
-from ._ops import Drc, Geometry, ProjectFused, Smooth, Splat, Transform
+from ._ops import Drc, Geometry, ProjectFused, SilhouetteLoss, Smooth, Splat, Transform
 
 __all__ = [
     "pointcloud_project_fast", "pointcloud_project", "pc_perspective_transform", "pointcloud2voxels3d_fast",
     "smoothen_voxels3d", "smooth_voxels3d", "smoothing_kernel", "gauss_kernel_1d", "separable_kernels",
     "drc_projection", "drc_event_probabilities", "drc_depth_projection", "drc_depth_grid", "pc_point_dropout",
     "quaternion_rotate", "quaternion_multiply", "quaternion_conjugate", "quaternion_normalise",
-    "get_smooth_sigma", "get_dropout_prob", "ProjectionOutputs",
+    "get_smooth_sigma", "get_dropout_prob", "ProjectionOutputs", "silhouette_loss",
 ]
 
 
@@ -309,6 +309,19 @@ def pc_point_dropout(points, rgb, keep_prob):
     out_points = points[rows, idx_t]
     out_rgb = rgb[rows, idx_t] if rgb is not None else None
     return out_points, out_rgb
+
+
+# ------------------------------------------------------------------------------------------------------
+# The caller's silhouette loss                       reference: dpc/models/model_pc_to.py:339-385, 410-440
+# ------------------------------------------------------------------------------------------------------
+def silhouette_loss(pred, gt, num_candidates=1):
+    """Projection loss of ModelPointCloud.add_proj_loss, fused with its gradient in one kernel.
+
+    pred [S*K,H,W,1] candidate silhouettes, gt [S,H,W,1] masks already pooled to H x W (the reference pools with
+    AvgPool2d and permutes first, model_pc_to.py:348-369).  K = 1: sum (gt-pred)^2 / S.  K > 1
+    (proj_loss_pose_candidates): per sample the candidate with the smallest sum of squared differences wins
+    and only winners contribute.  Returns (loss, winner [S] int32)."""
+    return SilhouetteLoss.apply(pred, gt, num_candidates)
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -25,7 +25,7 @@ SYMBOLS = (
     "dpc_abi_version", "dpc_strerror", "dpc_mask_words_per_plane", "dpc_workspace_bytes", "dpc_locate",
     "dpc_project_fwd", "dpc_project_bwd", "dpc_transform_fwd", "dpc_transform_bwd",
     "dpc_splat_fwd", "dpc_splat_bwd", "dpc_smooth", "dpc_drc_fwd", "dpc_drc_bwd",
-    "dpc_profile_enable", "dpc_profile_disable", "dpc_profile_count", "dpc_profile_get",
+    "dpc_silhouette_loss", "dpc_profile_enable", "dpc_profile_disable", "dpc_profile_count", "dpc_profile_get",
 )
 
 
@@ -78,6 +78,8 @@ def lib():
         L.dpc_profile_count.restype = ctypes.c_int
         L.dpc_profile_get.restype = ctypes.c_int
         L.dpc_profile_get.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float)]
+        L.dpc_silhouette_loss.restype = ctypes.c_int
+        L.dpc_silhouette_loss.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
         L.dpc_smooth.restype = ctypes.c_int
         L.dpc_smooth.argtypes = [pp, vp, vp, ctypes.c_int, vp, vp, vp, vp]
         if L.dpc_abi_version() != ABI_VERSION:

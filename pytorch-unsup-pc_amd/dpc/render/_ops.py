@@ -270,3 +270,34 @@ class Drc(torch.autograd.Function):
                                      N.ptr(dvox), N.stream_ptr(dev))
         N.check(rc, "dpc_drc_bwd")
         return _like_input(dvox, ctx.vox), None
+
+
+class SilhouetteLoss(torch.autograd.Function):
+    """add_proj_loss / proj_loss_pose_candidates fused with its gradient (one launch, gradient precomputed in
+    the forward; backward scales it by the incoming scalar)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt, num_candidates):
+        dev = N.require_device(pred, gt)
+        p32, g32 = _f32(pred), _f32(gt)
+        S = g32.shape[0]
+        K = int(num_candidates)
+        if p32.shape[0] != S * K:
+            raise ValueError("pred has %d silhouettes, expected %d samples x %d candidates" % (p32.shape[0], S, K))
+        n_pix = g32[0].numel() if S else 1
+        if S and p32[0].numel() != n_pix:
+            raise ValueError("gt and pred silhouettes differ in size: %s vs %s" % (tuple(g32.shape), tuple(p32.shape)))
+        part = torch.empty((S,), dtype=torch.float32, device=dev)
+        winner = torch.empty((S,), dtype=torch.int32, device=dev)
+        dpred = torch.empty_like(p32)
+        with torch.cuda.device(dev):
+            rc = N.lib().dpc_silhouette_loss(N.ptr(g32), N.ptr(p32), S, K, n_pix, N.ptr(part), N.ptr(winner), N.ptr(dpred),
+                                             N.stream_ptr(dev))
+        N.check(rc, "dpc_silhouette_loss")
+        ctx.dpred, ctx.meta = dpred, _meta(pred)
+        ctx.mark_non_differentiable(winner)
+        return part.sum(), winner
+
+    @staticmethod
+    def backward(ctx, dloss, _dwinner):
+        return _like_input(ctx.dpred * dloss, ctx.meta), None, None

@@ -376,6 +376,24 @@ def test_full_size_properties(R, O):
     close(g1[2][idx], cs.grad, 3e-5, "ds vs oracle at full size")
 
 
+def test_silhouette_loss_candidates(R, O, golden):
+    """Fused min-of-K loss + gradient vs proj_loss_pose_candidates of the reference (fixture F8), and K=1."""
+    g = golden("f8_candidates.npz")
+    pred = dev(g["pred"], True)
+    loss, win = R.silhouette_loss(pred, dev(g["gt"]), int(g["K"]))
+    close(loss, g["loss"], TOL, "candidate loss")
+    assert np.array_equal(win.cpu().numpy(), g["argmin"])
+    (3.0 * loss).backward()
+    close(pred.grad, 3.0 * g["dpred"], TOL, "candidate dpred")
+    pred1 = dev(g["pred"][::4], True)
+    gt = dev(g["gt"])
+    loss1, _ = R.silhouette_loss(pred1, gt)
+    ref = ((gt - pred1.detach()) ** 2).sum() / gt.shape[0]
+    close(loss1, ref, TOL, "K=1 loss")
+    loss1.backward()
+    close(pred1.grad, 2 * (pred1.detach() - gt) / gt.shape[0], TOL, "K=1 dpred")
+
+
 def test_point_dropout_matches_reference_rng(R):
     pts = torch.arange(2 * 10 * 3, dtype=torch.float32, device="cuda").reshape(2, 10, 3)
     np.random.seed(7)
