@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DPC_ABI_VERSION 2
+#define DPC_ABI_VERSION 3
 #define DPC_MAX_TAPS 63 /* longest 1-D smoothing kernel accepted (pc_gauss_kernel_size) */
 
 enum {
@@ -67,15 +67,18 @@ const char* dpc_strerror(int code);
 /* Words of the clamp mask ([B, D, dpc_mask_words_per_plane] uint64; bit i of a plane = voxel y*W+x == i,
  * set where the raw splat value v satisfies 0 <= v <= 1, the pass-through set of torch.clamp's backward). */
 size_t dpc_mask_words_per_plane(const DpcParams* p);
-/* Point records written by the locate kernel and consumed by the slab kernels: [B, N, DPC_CELL_INTS] int32
- * (packed cell index iz<<20|iy<<10|ix or -1, then the three fractional weights as fp32 bit patterns, encoded
- * so that both r and 1-r keep fp32 relative precision).  Opaque to the caller; saved between fwd and bwd. */
-#define DPC_CELL_INTS 4
+/* Binned point records written by the locate kernel and consumed by the slab kernels -- opaque to the caller,
+ * dpc_cells_bytes(p) bytes, saved between forward and backward.  Per cloud, ceil(N/256) chunks; each chunk holds
+ * its 256 points counting-sorted by z cell: 256 x {int32 code = iz<<20|iy<<10|ix or -1 (out of bounds), 3 x fp32
+ * fractional weights encoded so that both r and 1-r keep fp32 relative precision}, 256 x int32 original point
+ * index, (D+2) x uint16 bin offsets (padded to 16 bytes). */
+size_t dpc_cells_bytes(const DpcParams* p);
 /* First launch of the fused forward on its own: transform (the reference's exact op sequence, see
- * csrc/dpc_common.h) + cell location.  tr_pc [B,N,3] | NULL, cells [B,N,DPC_CELL_INTS].  Integer/bit-exact
- * against the reference: the parity tests compare `cells` with records computed from the oracle's fp64 tr_pc. */
+ * csrc/dpc_common.h) + cell location + per-256-point z sort.  tr_pc [B,N,3] | NULL, cells dpc_cells_bytes(p).
+ * Integer/bit-exact against the reference: the parity tests decode `cells` and compare with records computed
+ * from the oracle's fp64 tr_pc. */
 int dpc_locate(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, float* tr_pc,
-               int32_t* cells, void* stream);
+               void* cells, void* stream);
 /* Scratch the fused entry points need (one grid-sized fp32 buffer + per-tile partial sums). */
 size_t dpc_workspace_bytes(const DpcParams* p);
 
@@ -83,12 +86,12 @@ size_t dpc_workspace_bytes(const DpcParams* p);
  * Fused hot path: replaces pointcloud_project_fast (dpc/util/point_cloud_to.py:191-263) =
  * pc_perspective_transform (:118-178) -> pointcloud2voxels3d_fast (:10-87) -> clamp (:201) ->
  * smoothen_voxels3d (:90-103) -> scale+clamp (:218-222) -> drc_projection (dpc/util/drc.py:114-129) ->
- * flip (:242), in three launches (locate points in fp64 -> splat+W/H passes in LDS -> z column pass + DRC).
+ * flip (:242), in three launches (locate + z-sort points -> splat+W/H passes in LDS -> z column pass + DRC).
  *   pc [B,N,3], q [B,4], t [B,3]|NULL, f [B,1]|NULL, s [B,1]|NULL, host_kern_xy[taps_xy], host_kern_z[taps_z]
  *   (HOST pointers: the tap weights travel as kernel arguments)
  * outputs
  *   tr_pc    [B,N,3] (z,y,x) | NULL
- *   cells    [B,N,DPC_CELL_INTS] point records (saved for backward)
+ *   cells    dpc_cells_bytes(p) bytes of binned point records (saved for backward)
  *   raw      [B,D,H,W] unclamped splat | NULL (not needed by the backward)
  *   smoothed [B,D,H,W] grid after clamp + Gaussian, BEFORE the occupancy scale (saved for backward;
  *            voxels = s ? clamp(s*smoothed,0,1) : smoothed)
@@ -97,7 +100,7 @@ size_t dpc_workspace_bytes(const DpcParams* p);
  * ------------------------------------------------------------------------------------------------- */
 int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                     const float* s, const float* host_kern_xy, const float* host_kern_z, float* tr_pc,
-                    int32_t* cells, float* raw, float* smoothed, uint64_t* mask, float* proj, void* workspace,
+                    void* cells, float* raw, float* smoothed, uint64_t* mask, float* proj, void* workspace,
                     void* stream);
 
 /* Hand-written backward of the chain above (the reference relies on autograd).
@@ -107,7 +110,7 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
  *   dsmall [B,DPC_SMALL_COLS]: dq at cols 0-3, ds at 4, dt at 5-7, df at 8 (ds/dt/df only meaningful when
  *          the matching input was given); fully overwritten, needs no zeroing by the caller. */
 int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
-                    const float* s, const float* host_kern_xy, const float* host_kern_z, const int32_t* cells,
+                    const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
                     const float* smoothed, const uint64_t* mask, const float* dproj, float* dpc, float* dsmall,
                     void* workspace, void* stream);
 
@@ -126,8 +129,8 @@ int dpc_transform_bwd(const DpcParams* p, const float* pc, const float* q, const
 
 /* pointcloud2voxels3d_fast (dpc/util/point_cloud_to.py:10-87): trilinear scatter of already-transformed
  * points tr [B,N,3] (z,y,x; fp32, or fp64 when tr_is_f64 -- the reference's direct callers pass fp64) into
- * vox [B,D,H,W] (overwritten).  cells [B,N,DPC_CELL_INTS] is scratch for the point records. */
-int dpc_splat_fwd(const DpcParams* p, const void* tr, int tr_is_f64, int32_t* cells, float* vox, void* stream);
+ * vox [B,D,H,W] (overwritten).  cells (dpc_cells_bytes(p) bytes) is scratch for the point records. */
+int dpc_splat_fwd(const DpcParams* p, const void* tr, int tr_is_f64, void* cells, float* vox, void* stream);
 /* backward of the scatter: gather dvox [B,D,H,W] at the 8 corners -> dtr [B,N,3] (fp32). */
 int dpc_splat_bwd(const DpcParams* p, const void* tr, int tr_is_f64, const float* dvox, float* dtr, void* stream);
 

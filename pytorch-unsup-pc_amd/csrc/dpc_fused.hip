@@ -1,12 +1,15 @@
 // Fused hot path of the differentiable point-cloud projection for MI355X (gfx950).
 //
 // Replaces pointcloud_project_fast (dpc/util/point_cloud_to.py:191-263 of the reference) and its autograd
-// backward with four launches:
+// backward with five launches:
 //
-//   forward   k_splat_hw   one workgroup per (cloud, z-slab): transform the cloud's points, scatter the 8
-//                          trilinear corners into an LDS-resident slab with ds_add_f32, emit the clamp
-//                          mask (1 bit/voxel), clamp, run the W- and H-passes of the Gaussian in LDS and
-//                          store the slab once, coalesced.
+//   forward   k_locate     one lane per point: the reference's exact transform sequence + fp64 cell location,
+//                          then each 256-point block counting-sorts its records by z cell in LDS, so the
+//                          slab kernels read only the points that touch their slab.
+//             k_splat_hw   one workgroup per (cloud, z-slab): scatter the 8 trilinear corners of the slab's
+//                          points into an LDS-resident slab with ds_add_f32, emit the clamp mask
+//                          (1 bit/voxel), clamp, run the W- and H-passes of the Gaussian in LDS and store the
+//                          slab once, coalesced.
 //             k_zcol_fwd   one lane per (cloud, y, x) ray: the whole z column in registers; D-pass of the
 //                          Gaussian, occupancy scale + clamp, DRC transmittance product (fp64 register),
 //                          silhouette written with the row flip folded into the store.
@@ -15,6 +18,10 @@
 //             k_gather_hw  one workgroup per (cloud, z-slab + 1 halo plane): adjoint H-/W-passes in LDS,
 //                          clamp mask, trilinear gather of the 8 corners straight from LDS, transform
 //                          backward, wave/block reduction of the quaternion/translation/focal gradients.
+//
+// The slab kernels exist twice: a generic form (any H x W, runtime strides, bounds-checked windows) and a form
+// specialised at compile time for H = W = 32/64/128 (rows padded to 16-byte multiples with zero pads instead
+// of bounds checks, ds_read_b128 W-pass, packed-FMA H-pass over column pairs).
 //
 // HBM traffic per cloud: 16 G^3 B forward + 16 G^3 (+1 halo plane per slab) backward + O(N); the raw splat
 // grid never leaves LDS (only its 1-bit clamp mask does).
@@ -28,14 +35,136 @@ namespace {
 
 constexpr int kSlabThreads = 1024;
 constexpr int kColThreads = 256;
-constexpr int kL = 16;                               // outputs per thread in the in-LDS line convolutions
-constexpr int kLdsBudget = 160 * 1024 - 4096;        // slab bytes; the rest holds the reduction scratch
+constexpr int kLocThreads = 256;                     // points per locate block == points per sorted chunk
+constexpr int kL = 16;                               // outputs per thread in the generic in-LDS line convolutions
+constexpr int kLdsLimit = 160 * 1024;                // bytes of LDS a workgroup may use on gfx950
 constexpr int kRedFloats = 16 * (kSlabThreads / DPC_WAVE);
+constexpr int kLdsBudget = kLdsLimit - 4096;         // generic slab bytes; the rest holds the reduction scratch
 
-__device__ inline int odd_stride(int w) { return w | 1; }  // LDS row stride: odd => conflict-free column walks
+__device__ inline int odd_stride(int w) { return w | 1; }  // generic LDS row stride: odd => conflict-free column walks
 
 // ------------------------------------------------------------------------------------------------------
-// In-LDS separable passes over a slab laid out [nz][H][WP].
+// Binned point storage ("cells"): per cloud, ceil(N/256) chunks; chunk c holds the records of points
+// [256c, 256c+256) counting-sorted by bin (bin = z cell iz, or D for out-of-bounds points):
+//   [256 x PointRec (16 B)] [256 x int32 original point index] [(D+2) x uint16 bin start offsets, padded to 16 B]
+// offs[k] = first sorted position of bin k; offs[D+1] = number of points in the chunk.
+// ------------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t chunk_bytes(int D) {
+  return (size_t)kLocThreads * (sizeof(PointRec) + sizeof(int)) + (((size_t)(D + 2) * 2 + 15) / 16) * 16;
+}
+__host__ __device__ inline int num_chunks(int N) { return (N + kLocThreads - 1) / kLocThreads; }
+
+struct Cells {
+  const uint8_t* base;
+  size_t chunk;   // bytes per chunk
+  int nblk;       // chunks per cloud
+  __device__ const uint8_t* at(int b, int blk) const { return base + ((size_t)b * nblk + blk) * chunk; }
+  __device__ const PointRec* recs(int b, int blk) const { return reinterpret_cast<const PointRec*>(at(b, blk)); }
+  __device__ const int* perm(int b, int blk) const {
+    return reinterpret_cast<const int*>(at(b, blk) + (size_t)kLocThreads * sizeof(PointRec));
+  }
+  __device__ const uint16_t* offs(int b, int blk) const {
+    return reinterpret_cast<const uint16_t*>(at(b, blk) + (size_t)kLocThreads * (sizeof(PointRec) + sizeof(int)));
+  }
+};
+
+// Visit every record of cloud b whose bin lies in [bin_lo, bin_hi): waves take chunks round-robin, lanes take
+// consecutive sorted positions.  f(rec, original_index).
+template <class F>
+__device__ inline void for_each_record(const Cells& cells, int b, int bin_lo, int bin_hi, F f) {
+  const int lane = threadIdx.x & (DPC_WAVE - 1), wave = threadIdx.x / DPC_WAVE, nw = blockDim.x / DPC_WAVE;
+  for (int blk = wave; blk < cells.nblk; blk += nw) {
+    const uint16_t* offs = cells.offs(b, blk);
+    const int beg = __builtin_amdgcn_readfirstlane((int)offs[bin_lo]);
+    const int end = __builtin_amdgcn_readfirstlane((int)offs[bin_hi]);
+    const PointRec* recs = cells.recs(b, blk);
+    const int* perm = cells.perm(b, blk);
+    for (int j = beg + lane; j < end; j += DPC_WAVE) f(load_record(recs, j), perm[j]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Forward 0: per-point transform (reference-exact op sequence) + fp64 cell location + per-block z-sort.
+//   grid (ceil(N/256), B), 256 threads.
+//   SRC = 0: pc/q/t/f -> camera transform (pc_perspective_transform), optional tr_pc output
+//   SRC = 1: points are already transformed, fp32 (z,y,x);  SRC = 2: same, fp64
+// ------------------------------------------------------------------------------------------------------
+template <int SRC>
+__global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void* __restrict__ pts,
+                                                        const float* __restrict__ q, const float* __restrict__ t,
+                                                        const float* __restrict__ f, float* __restrict__ tr_pc,
+                                                        uint8_t* __restrict__ cells_out) {
+  __shared__ int hist[1026];  // D + 2 <= 1026 bins (validate() caps D at 1024)
+  __shared__ CameraRef cam_s;
+  const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+  const int D = P.D, nbins = D + 1;
+  const int i = blk * kLocThreads + tid;
+  const bool live = i < P.N;
+  for (int k = tid; k < nbins + 1; k += kLocThreads) hist[k] = 0;
+  if (SRC == 0 && tid == 0) cam_s = load_camera_ref(P, q, t, f, b);  // one normalisation per block
+  __syncthreads();
+
+  PointRec rec;
+  rec.code = -1; rec.tz = rec.ty = rec.tx = 0.f;
+  if (live) {
+    const size_t idx = (size_t)b * P.N + i;
+    double Z, Y, X;
+    if (SRC == 0) {
+      const float* p = static_cast<const float*>(pts) + idx * 3;
+      project_point_ref(cam_s, p[0], p[1], p[2], Z, Y, X);
+      if (tr_pc != nullptr) {
+        tr_pc[idx * 3 + 0] = (float)Z; tr_pc[idx * 3 + 1] = (float)Y; tr_pc[idx * 3 + 2] = (float)X;
+      }
+    } else if (SRC == 1) {
+      const float* p = static_cast<const float*>(pts) + idx * 3;
+      Z = p[0]; Y = p[1]; X = p[2];
+    } else {
+      const double* p = static_cast<const double*>(pts) + idx * 3;
+      Z = p[0]; Y = p[1]; X = p[2];
+    }
+    rec = make_record(Z, Y, X, P.D, P.H, P.W);
+  }
+  const int bin = rec.code < 0 ? D : (rec.code >> 20);
+  int rank = 0;
+  if (live) rank = atomicAdd(&hist[bin], 1);  // ds_add_rtn_u32: position inside the bin
+  __syncthreads();
+
+  // exclusive prefix over the bins by the first wave: lane l owns bins [l*C, (l+1)*C)
+  if (tid < DPC_WAVE) {
+    const int C = (nbins + DPC_WAVE - 1) / DPC_WAVE;
+    int sum = 0;
+    for (int k = tid * C; k < min((tid + 1) * C, nbins); ++k) sum += hist[k];
+    int incl = sum;
+#pragma unroll
+    for (int off = 1; off < DPC_WAVE; off <<= 1) {
+      const int up = __shfl_up(incl, off, DPC_WAVE);
+      if (tid >= off) incl += up;
+    }
+    int run = incl - sum;
+    for (int k = tid * C; k < min((tid + 1) * C, nbins); ++k) {
+      const int c = hist[k];
+      hist[k] = run;
+      run += c;
+    }
+    if (tid == DPC_WAVE - 1) hist[nbins] = incl;  // total
+  }
+  __syncthreads();
+
+  const size_t chunk = chunk_bytes(D);
+  uint8_t* out = cells_out + ((size_t)b * gridDim.x + blk) * chunk;
+  if (live) {
+    const int pos = hist[bin] + rank;
+    int4 v;
+    v.x = rec.code; v.y = __float_as_int(rec.tz); v.z = __float_as_int(rec.ty); v.w = __float_as_int(rec.tx);
+    reinterpret_cast<int4*>(out)[pos] = v;
+    reinterpret_cast<int*>(out + (size_t)kLocThreads * sizeof(PointRec))[pos] = i;
+  }
+  uint16_t* offs = reinterpret_cast<uint16_t*>(out + (size_t)kLocThreads * (sizeof(PointRec) + sizeof(int)));
+  for (int k = tid; k < nbins + 1; k += kLocThreads) offs[k] = (uint16_t)hist[k];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Generic in-LDS separable passes over a slab laid out [nz][H][WP] (runtime dims, bounds-checked windows).
 // Every thread owns (line, segment-of-kL-outputs); all windows are read, then a barrier, then written back,
 // so the pass is in place.  Lanes map to consecutive lines (W-pass: stride WP odd; H-pass: consecutive x),
 // which keeps ds_read_b32/ds_write_b32 bank-conflict free.
@@ -88,107 +217,261 @@ __device__ inline void hpass(float* slab, int nz, int H, int W, int WP, const Ta
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Forward 0: per-point transform (reference-exact op sequence) + cell location in fp64, once per point.          grid (ceil(N/256), B)
-//   SRC = 0: pc/q/t/f -> camera transform (pc_perspective_transform), optional tr_pc output
-//   SRC = 1: points are already transformed, fp32 (z,y,x);  SRC = 2: same, fp64
+// Specialised slab geometry: H = W = GS known at compile time.
+//   row layout   [PAD zeros][GS values], PAD = max(4, RB rounded up to 4): rows start 16-byte aligned, the
+//                zero pad of row r+1 doubles as the right halo of row r, so W-windows need no bounds checks
+//   W-pass       thread = (row, 32-output segment); lanes walk consecutive rows (stride GS+PAD floats keeps
+//                ds_read_b128 / ds_write_b128 conflict-free for PAD = 4)
+//   H-pass       thread = (plane, column PAIR, 16-output segment); ds_read_b64 of two adjacent columns and
+//                packed v_pk_fma_f32 on the pair
 // ------------------------------------------------------------------------------------------------------
-template <int SRC>
-__global__ __launch_bounds__(256) void k_locate(DpcParams P, const void* __restrict__ pts, const float* __restrict__ q,
-                                                const float* __restrict__ t, const float* __restrict__ f,
-                                                float* __restrict__ tr_pc, PointRec* __restrict__ recs) {
-  const int b = blockIdx.y;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P.N) return;
-  const size_t idx = (size_t)b * P.N + i;
-  double Z, Y, X;
-  if (SRC == 0) {
-    const CameraRef cam = load_camera_ref(P, q, t, f, b);
-    const float* p = static_cast<const float*>(pts) + idx * 3;
-    project_point_ref(cam, p[0], p[1], p[2], Z, Y, X);
-    if (tr_pc != nullptr) {
-      tr_pc[idx * 3 + 0] = (float)Z; tr_pc[idx * 3 + 1] = (float)Y; tr_pc[idx * 3 + 2] = (float)X;
-    }
-  } else if (SRC == 1) {
-    const float* p = static_cast<const float*>(pts) + idx * 3;
-    Z = p[0]; Y = p[1]; X = p[2];
-  } else {
-    const double* p = static_cast<const double*>(pts) + idx * 3;
-    Z = p[0]; Y = p[1]; X = p[2];
-  }
-  recs[idx] = make_record(Z, Y, X, P.D, P.H, P.W);
-}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// ------------------------------------------------------------------------------------------------------
-// Forward 1: splat + mask + clamp + W/H Gaussian passes.                          grid (nslab, B)
-//   Tbuf == nullptr: stage-level pointcloud2voxels3d_fast, only `raw` is written.
-// ------------------------------------------------------------------------------------------------------
-template <int RB>
-__global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, const PointRec* __restrict__ recs,
-                                                           TapsT<RB> taps, int Zs, float* __restrict__ raw,
-                                                           float* __restrict__ Tbuf, uint64_t* __restrict__ mask) {
-  extern __shared__ __attribute__((aligned(16))) float slab[];
-  const int D = P.D, H = P.H, W = P.W, N = P.N;
-  const int WP = odd_stride(W);
-  const int b = blockIdx.y, z0 = blockIdx.x * Zs;
-  const int nz = min(Zs, D - z0);
-  const int tid = threadIdx.x, nthr = blockDim.x;
+template <int GS, int RB>
+struct SlabGeo {
+  static constexpr int PAD = RB <= 4 ? 4 : ((RB + 3) / 4) * 4;
+  static constexpr int WP = GS + PAD;
+  static constexpr int PLANE = GS * WP;
+  static constexpr int LW = 32, NSEGW = GS / LW, LWIN = LW + 2 * PAD;   // W-pass
+  static constexpr int LH = 16, NSEGH = GS / LH, XP = GS / 2, HWIN = LH + 2 * RB;  // H-pass
+  static constexpr int NT = GS >= 64 ? 1024 : 256;
+  __host__ __device__ static constexpr size_t slab_floats(int planes) { return (size_t)planes * PLANE + PAD; }
+  __device__ static int at(int z, int y, int x) { return (z * GS + y) * WP + PAD + x; }
+};
 
-  for (int i = tid; i < nz * H * WP; i += nthr) slab[i] = 0.f;
-  __syncthreads();
-
-  const PointRec* cloud = recs + (size_t)b * N;
-  for (int i = tid; i < N; i += nthr) {
-    const PointRec rec = load_record(cloud, i);
-    if (rec.code < 0) continue;
-    const Cell c = cell_from_record(rec);
-    if (c.iz + 1 < z0 || c.iz >= z0 + nz) continue;
+// In-place W-pass over NPL planes.  MASK: 0 none, 1 emit the clamp mask from the raw values (forward),
+// 2 multiply the outputs by the stored mask bits (backward).  mask32 points at this slab's first plane.
+template <int GS, int RB, int NPL, bool CLAMP1, int MASK>
+__device__ inline void wpass_fast(float* slab, const TapsT<RB>& taps, uint32_t* mask32, int planes_present) {
+  using Geo = SlabGeo<GS, RB>;
+  constexpr int ROWS = NPL * GS, ITEMS = ROWS * Geo::NSEGW, IPT = (ITEMS + Geo::NT - 1) / Geo::NT;
+  float v[IPT][Geo::LWIN];
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int zz = c.iz + k - z0;
-      if (zz < 0 || zz >= nz) continue;
+  for (int it = 0; it < IPT; ++it) {
+    const int item = threadIdx.x + it * Geo::NT;
+    if (item < ITEMS) {
+      const int row = item % ROWS, seg = item / ROWS;
+      const f32x4* src = reinterpret_cast<const f32x4*>(slab + row * Geo::WP + seg * Geo::LW);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int yy = c.iy + j;
-        if (yy >= H) continue;
-#pragma unroll
-        for (int i2 = 0; i2 < 2; ++i2) {
-          const int xx = c.ix + i2;
-          if (xx >= W) continue;
-          atomicAdd(&slab[(zz * H + yy) * WP + xx], c.wz[k] * c.wy[j] * c.wx[i2]);  // ds_add_f32
-        }
+      for (int k = 0; k < Geo::LWIN / 4; ++k) {
+        const f32x4 q = src[k];
+        v[it][4 * k + 0] = q.x; v[it][4 * k + 1] = q.y; v[it][4 * k + 2] = q.z; v[it][4 * k + 3] = q.w;
       }
     }
   }
   __syncthreads();
-
-  // clamp mask (bit set <=> raw <= 1; raw >= 0 always) and, when asked for, the raw grid itself
-  {
-    const int HW = H * W, wpp = (HW + 63) / 64;
-    const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
-    for (int item = wave; item < nz * wpp; item += nw) {
-      const int z = item / wpp, c = item - z * wpp;
-      const int idx = c * 64 + lane;
-      const bool in = idx < HW;
-      const int y = idx / W, x = idx - y * W;
-      const float v = in ? slab[(z * H + y) * WP + x] : 2.f;
-      const unsigned long long bits = __ballot(in && v <= 1.0f);
-      if (mask != nullptr && lane == 0) mask[((size_t)b * D + z0 + z) * wpp + c] = bits;
-      if (raw != nullptr && in) raw[((size_t)b * D + z0 + z) * HW + idx] = v;
+#pragma unroll
+  for (int it = 0; it < IPT; ++it) {
+    const int item = threadIdx.x + it * Geo::NT;
+    if (item < ITEMS) {
+      const int row = item % ROWS, seg = item / ROWS;
+      const int z = row / GS;
+      uint32_t bits = 0xffffffffu;
+      if (MASK == 1) {
+        bits = 0u;
+#pragma unroll
+        for (int j = 0; j < Geo::LW; ++j) bits |= (v[it][Geo::PAD + j] <= 1.0f ? 1u : 0u) << j;
+        if (z < planes_present) mask32[(size_t)row * Geo::NSEGW + seg] = bits;
+      } else if (MASK == 2) {
+        bits = z < planes_present ? mask32[(size_t)row * Geo::NSEGW + seg] : 0u;
+      }
+      if (CLAMP1) {
+#pragma unroll
+        for (int k = 0; k < Geo::LWIN; ++k) v[it][k] = fminf(v[it][k], 1.0f);
+      }
+      f32x4* dst = reinterpret_cast<f32x4*>(slab + row * Geo::WP + Geo::PAD + seg * Geo::LW);
+#pragma unroll
+      for (int k = 0; k < Geo::LW / 4; ++k) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = 4 * k + e;
+          float acc = 0.f;
+#pragma unroll
+          for (int tp = 0; tp < 2 * RB + 1; ++tp) acc = fmaf(taps.w[tp], v[it][j + tp + Geo::PAD - RB], acc);
+          o[e] = (MASK == 2 && !((bits >> j) & 1u)) ? 0.f : acc;
+        }
+        f32x4 q;
+        q.x = o[0]; q.y = o[1]; q.z = o[2]; q.w = o[3];
+        dst[k] = q;
+      }
     }
   }
-  if (Tbuf == nullptr) return;
+  __syncthreads();
+}
 
-  float* Tout = Tbuf + ((size_t)b * D + z0) * H * W;
-  if (RB == 0) {  // no smoothing (centre tap 1) or a kernel trimmed to its centre tap: T = w0^2 clamp(raw, 0, 1)
-    const float w2 = taps.w[0] * taps.w[0];
-    for (int i = tid; i < nz * H * W; i += nthr) {
-      const int x = i % W, zy = i / W;
-      Tout[i] = w2 * fminf(slab[zy * WP + x], 1.0f);
+// H-pass over NPL planes, two adjacent columns per thread.  store(z, y, x_even, pair) consumes the results;
+// INPLACE inserts the barrier between the window reads and the stores.
+template <int GS, int RB, int NPL, bool INPLACE, class Store>
+__device__ inline void hpass_fast(const float* slab, const TapsT<RB>& taps, Store store) {
+  using Geo = SlabGeo<GS, RB>;
+  constexpr int ITEMS = NPL * Geo::XP * Geo::NSEGH, IPT = (ITEMS + Geo::NT - 1) / Geo::NT;
+  f32x2 v[IPT][Geo::HWIN];
+#pragma unroll
+  for (int it = 0; it < IPT; ++it) {
+    const int item = threadIdx.x + it * Geo::NT;
+    if (item < ITEMS) {
+      const int xp = item % Geo::XP, rest = item / Geo::XP;
+      const int z = rest % NPL, seg = rest / NPL;
+      const bool lo = seg == 0, hi = seg == Geo::NSEGH - 1;
+      const float* col = slab + Geo::at(z, 0, 2 * xp);
+      const int y0 = seg * Geo::LH - RB;
+#pragma unroll
+      for (int i = 0; i < Geo::HWIN; ++i) {
+        // only the first/last RB rows of a window can fall outside the plane (zero padding): clamp the
+        // address, then zero the value
+        const bool out = (i < RB && lo) || (i >= Geo::LH + RB && hi);
+        const int y = out ? 0 : y0 + i;
+        f32x2 q = *reinterpret_cast<const f32x2*>(col + y * Geo::WP);
+        if (out) q = f32x2{0.f, 0.f};
+        v[it][i] = q;
+      }
     }
-    return;
   }
-  wpass_inplace<RB, true>(slab, nz, H, W, WP, taps, [](int, int, float v) { return v; });
-  hpass<RB>(slab, nz, H, W, WP, taps, [&](int z, int y, int x, float v) { Tout[(z * H + y) * W + x] = v; });
+  if (INPLACE) __syncthreads();
+#pragma unroll
+  for (int it = 0; it < IPT; ++it) {
+    const int item = threadIdx.x + it * Geo::NT;
+    if (item < ITEMS) {
+      const int xp = item % Geo::XP, rest = item / Geo::XP;
+      const int z = rest % NPL, seg = rest / NPL;
+#pragma unroll
+      for (int j = 0; j < Geo::LH; ++j) {
+        f32x2 acc = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int tp = 0; tp < 2 * RB + 1; ++tp)
+          acc = __builtin_elementwise_fma(f32x2{taps.w[tp], taps.w[tp]}, v[it][j + tp], acc);
+        store(z, seg * Geo::LH + j, 2 * xp, acc);
+      }
+    }
+  }
+  if (INPLACE) __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Forward 1: splat + mask + clamp + W/H Gaussian passes.                          grid (nslab, B)
+//   GS = 0: generic (runtime dims, Zs = zs_rt);  GS > 0: specialised, ZS planes per slab.
+//   Tbuf == nullptr: stage-level pointcloud2voxels3d_fast, only `raw` is written.
+// ------------------------------------------------------------------------------------------------------
+template <int GS, int ZS, int RB>
+__global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells cells, TapsT<RB> taps, int zs_rt,
+                                                           float* __restrict__ raw, float* __restrict__ Tbuf,
+                                                           uint64_t* __restrict__ mask) {
+  extern __shared__ __attribute__((aligned(16))) float slab[];
+  const int D = P.D, H = P.H, W = P.W;
+  const int Zs = GS ? ZS : zs_rt;
+  const int b = blockIdx.y, z0 = blockIdx.x * Zs;
+  const int nz = min(Zs, D - z0);
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const size_t HW = (size_t)H * W;
+
+  if constexpr (GS > 0) {
+    using Geo = SlabGeo<GS, RB>;
+    f32x4* s4 = reinterpret_cast<f32x4*>(slab);
+    for (int i = tid; i < (int)(Geo::slab_floats(ZS) / 4); i += Geo::NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, [&](const PointRec& rec, int) {
+      const Cell c = cell_from_record(rec);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int zz = c.iz + k - z0;
+        if (zz < 0 || zz >= nz) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (c.iy + j >= GS) continue;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            if (c.ix + e >= GS) continue;
+            atomicAdd(&slab[Geo::at(zz, c.iy + j, c.ix + e)], c.wz[k] * c.wy[j] * c.wx[e]);  // ds_add_f32
+          }
+        }
+      }
+    });
+    __syncthreads();
+    if (raw != nullptr) {  // stage-level splat: the raw grid itself
+      float* dst = raw + ((size_t)b * D + z0) * HW;
+      for (int i = tid; i < nz * GS * (GS / 4); i += Geo::NT) {
+        const int x4 = i % (GS / 4), zy = i / (GS / 4);
+        *reinterpret_cast<f32x4*>(dst + (size_t)zy * GS + 4 * x4) =
+            *reinterpret_cast<const f32x4*>(slab + zy * Geo::WP + Geo::PAD + 4 * x4);
+      }
+    }
+    if (Tbuf == nullptr) return;
+    uint32_t* mask32 = reinterpret_cast<uint32_t*>(mask + ((size_t)b * D + z0) * ((HW + 63) / 64));
+    float* Tout = Tbuf + ((size_t)b * D + z0) * HW;
+    if constexpr (RB == 0) {
+      // no smoothing (centre tap 1) or a kernel trimmed to its centre tap: T = w0^2 clamp(raw,0,1) + the mask
+      const float w2 = taps.w[0] * taps.w[0];
+      const int lane = tid & 63;
+      for (int i = tid; i < ZS * GS * GS; i += Geo::NT) {
+        const int x = i % GS, zy = i / GS, z = zy / GS;
+        const float vraw = slab[zy * Geo::WP + Geo::PAD + x];
+        const unsigned long long bits = __ballot(vraw <= 1.0f);
+        if (z < nz) {
+          if (lane == 0) reinterpret_cast<unsigned long long*>(mask32)[i >> 6] = bits;
+          Tout[i] = w2 * fminf(vraw, 1.0f);
+        }
+      }
+      return;
+    } else {
+      wpass_fast<GS, RB, ZS, true, 1>(slab, taps, mask32, nz);
+      hpass_fast<GS, RB, ZS, false>(slab, taps, [&](int z, int y, int x, f32x2 val) {
+        if (z < nz) *reinterpret_cast<f32x2*>(Tout + ((size_t)z * GS + y) * GS + x) = val;
+      });
+    }
+  } else {
+    const int WP = odd_stride(W);
+    for (int i = tid; i < nz * H * WP; i += nthr) slab[i] = 0.f;
+    __syncthreads();
+    for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, [&](const PointRec& rec, int) {
+      const Cell c = cell_from_record(rec);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int zz = c.iz + k - z0;
+        if (zz < 0 || zz >= nz) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int yy = c.iy + j;
+          if (yy >= H) continue;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int xx = c.ix + e;
+            if (xx >= W) continue;
+            atomicAdd(&slab[(zz * H + yy) * WP + xx], c.wz[k] * c.wy[j] * c.wx[e]);  // ds_add_f32
+          }
+        }
+      }
+    });
+    __syncthreads();
+    // clamp mask (bit set <=> raw <= 1; raw >= 0 always) and, when asked for, the raw grid itself
+    {
+      const int iHW = H * W, wpp = (iHW + 63) / 64;
+      const int lane = tid & 63, wave = tid >> 6, nw = nthr >> 6;
+      for (int item = wave; item < nz * wpp; item += nw) {
+        const int z = item / wpp, c = item - z * wpp;
+        const int idx = c * 64 + lane;
+        const bool in = idx < iHW;
+        const int y = idx / W, x = idx - y * W;
+        const float vraw = in ? slab[(z * H + y) * WP + x] : 2.f;
+        const unsigned long long bits = __ballot(in && vraw <= 1.0f);
+        if (mask != nullptr && lane == 0) mask[((size_t)b * D + z0 + z) * wpp + c] = bits;
+        if (raw != nullptr && in) raw[((size_t)b * D + z0 + z) * iHW + idx] = vraw;
+      }
+    }
+    if (Tbuf == nullptr) return;
+    float* Tout = Tbuf + ((size_t)b * D + z0) * HW;
+    if (RB == 0) {
+      const float w2 = taps.w[0] * taps.w[0];
+      for (int i = tid; i < nz * H * W; i += nthr) {
+        const int x = i % W, zy = i / W;
+        Tout[i] = w2 * fminf(slab[zy * WP + x], 1.0f);
+      }
+      return;
+    }
+    wpass_inplace<RB, true>(slab, nz, H, W, WP, taps, [](int, int, float val) { return val; });
+    hpass<RB>(slab, nz, H, W, WP, taps, [&](int z, int y, int x, float val) { Tout[(z * H + y) * W + x] = val; });
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -422,94 +705,131 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHo
 // Backward 2: adjoint H/W passes + clamp mask + trilinear gather + transform backward.   grid (nslab, B)
 //   The slab holds cell layers [z0, z0+Zs) plus one halo plane so each point's 8 corners are local.
 // ------------------------------------------------------------------------------------------------------
-template <int RB>
-__global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, const PointRec* __restrict__ recs,
-                                                            const float* __restrict__ pc,
+template <int GS, int ZS, int RB>
+__global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells cells, const float* __restrict__ pc,
                                                             const float* __restrict__ q, const float* __restrict__ t,
-                                                            const float* __restrict__ f, TapsT<RB> taps_adj, int Zs,
+                                                            const float* __restrict__ f, TapsT<RB> taps_adj, int zs_rt,
                                                             const float* __restrict__ dT,
                                                             const uint64_t* __restrict__ mask,
                                                             const float* __restrict__ ds_part, int n_ds_part,
                                                             float* __restrict__ dpc, float* __restrict__ dsmall) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
   const int D = P.D, H = P.H, W = P.W, N = P.N, HW = H * W;
-  const int WP = odd_stride(W);
+  const int Zs = GS ? ZS : zs_rt;
   const int b = blockIdx.y, z0 = blockIdx.x * Zs;
   const int nzp = min(Zs + 1, D - z0);  // planes present (cell layers + halo)
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int wpp = (HW + 63) / 64;
-  float* red = slab + (size_t)(Zs + 1) * H * WP;
-
   const float* src = dT + ((size_t)b * D + z0) * HW;
-  for (int i = tid; i < nzp * HW; i += nthr) {
-    const int x = i % W, zy = i / W;
-    slab[zy * WP + x] = src[i];
-  }
-  __syncthreads();
-
   const uint64_t* mrow = mask + ((size_t)b * D + z0) * wpp;
-  if (RB == 0) {
-    const float w2 = taps_adj.w[0] * taps_adj.w[0];
-    for (int i = tid; i < nzp * HW; i += nthr) {
-      const int z = i / HW, r = i - z * HW;
-      const int x = r % W, y = r / W;
-      const bool pass = (mrow[(size_t)z * wpp + (r >> 6)] >> (r & 63)) & 1ull;
-      slab[(z * H + y) * WP + x] = pass ? w2 * slab[(z * H + y) * WP + x] : 0.f;
+  float* red;
+
+  if constexpr (GS > 0) {
+    using Geo = SlabGeo<GS, RB>;
+    constexpr int NPL = ZS + 1;
+    red = slab + ((Geo::slab_floats(NPL) + 3) / 4) * 4;
+    // planes -> LDS (16-byte global loads, 16-byte LDS stores); absent planes and the row pads are zeroed
+    for (int i = tid; i < NPL * GS * (GS / 4); i += Geo::NT) {
+      const int x4 = i % (GS / 4), zy = i / (GS / 4);
+      f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (zy < nzp * GS) val = *reinterpret_cast<const f32x4*>(src + (size_t)zy * GS + 4 * x4);
+      *reinterpret_cast<f32x4*>(slab + zy * Geo::WP + Geo::PAD + 4 * x4) = val;
+    }
+    for (int i = tid; i < (NPL * GS + 1) * (Geo::PAD / 4); i += Geo::NT) {
+      const int p4 = i % (Geo::PAD / 4), row = i / (Geo::PAD / 4);
+      *reinterpret_cast<f32x4*>(slab + row * Geo::WP + 4 * p4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
+    const uint32_t* mask32 = reinterpret_cast<const uint32_t*>(mrow);
+    if constexpr (RB == 0) {
+      const float w2 = taps_adj.w[0] * taps_adj.w[0];
+      for (int i = tid; i < NPL * GS * GS; i += Geo::NT) {
+        const int x = i % GS, zy = i / GS;
+        const bool pass = zy < nzp * GS && ((mask32[i >> 5] >> (i & 31)) & 1u);
+        float* cell = slab + zy * Geo::WP + Geo::PAD + x;
+        *cell = pass ? w2 * *cell : 0.f;
+      }
+      __syncthreads();
+    } else {
+      hpass_fast<GS, RB, NPL, true>(slab, taps_adj, [&](int z, int y, int x, f32x2 val) {
+        *reinterpret_cast<f32x2*>(slab + Geo::at(z, y, x)) = val;
+      });
+      wpass_fast<GS, RB, NPL, false, 2>(slab, taps_adj, const_cast<uint32_t*>(mask32), nzp);
+    }
   } else {
-    hpass<RB>(slab, nzp, H, W, WP, taps_adj, [&](int z, int y, int x, float v) { slab[(z * H + y) * WP + x] = v; });
-    wpass_inplace<RB, false>(slab, nzp, H, W, WP, taps_adj, [&](int line, int x, float v) {
-      const int z = line / H, y = line - z * H;
-      const int bit = y * W + x;
-      return ((mrow[(size_t)z * wpp + (bit >> 6)] >> (bit & 63)) & 1ull) ? v : 0.f;
-    });
+    const int WP = odd_stride(W);
+    red = slab + (size_t)(Zs + 1) * H * WP;
+    for (int i = tid; i < nzp * HW; i += nthr) {
+      const int x = i % W, zy = i / W;
+      slab[zy * WP + x] = src[i];
+    }
+    __syncthreads();
+    if (RB == 0) {
+      const float w2 = taps_adj.w[0] * taps_adj.w[0];
+      for (int i = tid; i < nzp * HW; i += nthr) {
+        const int z = i / HW, r = i - z * HW;
+        const int x = r % W, y = r / W;
+        const bool pass = (mrow[(size_t)z * wpp + (r >> 6)] >> (r & 63)) & 1ull;
+        slab[(z * H + y) * WP + x] = pass ? w2 * slab[(z * H + y) * WP + x] : 0.f;
+      }
+      __syncthreads();
+    } else {
+      hpass<RB>(slab, nzp, H, W, WP, taps_adj, [&](int z, int y, int x, float val) { slab[(z * H + y) * WP + x] = val; });
+      wpass_inplace<RB, false>(slab, nzp, H, W, WP, taps_adj, [&](int line, int x, float val) {
+        const int z = line / H, y = line - z * H;
+        const int bit = y * W + x;
+        return ((mrow[(size_t)z * wpp + (bit >> 6)] >> (bit & 63)) & 1ull) ? val : 0.f;
+      });
+    }
   }
 
+  // gather: every in-bounds point belongs to the slab of its cell layer iz; slab 0 also zero-fills the
+  // gradient of the out-of-bounds points (bin D)
   const Camera cam = load_camera(P, q, t, f, b);
   CamGrad g;
   camgrad_zero(g);
   const float* cloud = pc + (size_t)b * N * 3;
   float* dcloud = dpc + (size_t)b * N * 3;
-  const PointRec* crecs = recs + (size_t)b * N;
-  for (int i = tid; i < N; i += nthr) {
-    const Cell c = cell_from_record(load_record(crecs, i));
-    const bool mine = c.valid ? (c.iz >= z0 && c.iz < z0 + Zs) : (blockIdx.x == 0);
-    if (!mine) continue;
-    float dpx = 0.f, dpy = 0.f, dpz = 0.f;
-    if (c.valid) {
-      float cv[2][2][2];
+  auto corner = [&](int zz, int yy, int xx) -> float {
+    if constexpr (GS > 0) return slab[SlabGeo<GS, RB>::at(zz, yy, xx)];
+    else return slab[(zz * H + yy) * odd_stride(W) + xx];
+  };
+  for_each_record(cells, b, z0, min(z0 + Zs, D), [&](const PointRec& rec, int i) {
+    const Cell c = cell_from_record(rec);
+    float cv[2][2][2];
 #pragma unroll
-      for (int k = 0; k < 2; ++k)
+    for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int i2 = 0; i2 < 2; ++i2) {
-            const bool ok = (c.iz + k < D) && (c.iy + j < H) && (c.ix + i2 < W);
-            cv[k][j][i2] = ok ? slab[((c.iz - z0 + k) * H + c.iy + j) * WP + c.ix + i2] : 0.f;
-          }
-      float dgz = 0.f, dgy = 0.f, dgx = 0.f;
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          dgz += (cv[1][a][e] - cv[0][a][e]) * c.wy[a] * c.wx[e];
-          dgy += (cv[a][1][e] - cv[a][0][e]) * c.wz[a] * c.wx[e];
-          dgx += (cv[a][e][1] - cv[a][e][0]) * c.wz[a] * c.wy[e];
+          const bool ok = (c.iz + k < D) && (c.iy + j < H) && (c.ix + e < W);
+          cv[k][j][e] = ok ? corner(c.iz - z0 + k, c.iy + j, c.ix + e) : 0.f;
         }
-      const float px = cloud[3 * i + 0], py = cloud[3 * i + 1], pz = cloud[3 * i + 2];
-      const Projected o = project_point(cam, px, py, pz);
-      project_point_bwd(cam, o, px, py, pz, dgz * (float)(D - 1), dgy * (float)(H - 1), dgx * (float)(W - 1), dpx, dpy,
-                        dpz, g);
-    }
+    float dgz = 0.f, dgy = 0.f, dgx = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        dgz += (cv[1][a][e] - cv[0][a][e]) * c.wy[a] * c.wx[e];
+        dgy += (cv[a][1][e] - cv[a][0][e]) * c.wz[a] * c.wx[e];
+        dgx += (cv[a][e][1] - cv[a][e][0]) * c.wz[a] * c.wy[e];
+      }
+    const float px = cloud[3 * i + 0], py = cloud[3 * i + 1], pz = cloud[3 * i + 2];
+    const Projected o = project_point(cam, px, py, pz);
+    float dpx, dpy, dpz;
+    project_point_bwd(cam, o, px, py, pz, dgz * (float)(D - 1), dgy * (float)(H - 1), dgx * (float)(W - 1), dpx, dpy, dpz, g);
     dcloud[3 * i + 0] = dpx; dcloud[3 * i + 1] = dpy; dcloud[3 * i + 2] = dpz;
-  }
+  });
+  if (blockIdx.x == 0)
+    for_each_record(cells, b, D, D + 1, [&](const PointRec&, int i) {
+      dcloud[3 * i + 0] = 0.f; dcloud[3 * i + 1] = 0.f; dcloud[3 * i + 2] = 0.f;
+    });
 
   float vals[13];
 #pragma unroll
   for (int i = 0; i < 9; ++i) vals[i] = g.m[i];
   vals[9] = g.dt[0]; vals[10] = g.dt[1]; vals[11] = g.dt[2]; vals[12] = g.df;
-  __syncthreads();  // slab reads done before the scratch tail is reused (it is disjoint, but keep phases apart)
   block_sum<13>(vals, red);
   if (tid == 0) {
     float dq[4];
@@ -534,7 +854,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, const P
 struct TapPlan {
   int taps;    // original length
   int radius;  // effective radius after dropping negligible outer taps
-  int bucket;  // compile-time radius bucket, -1 = needs the generic kernel
+  int bucket;  // compile-time radius bucket, -1 = needs the generic column kernel / staged path
 };
 
 // Outer taps whose total |weight| is below 1e-8 of the kernel's mass change no fp32 result at the 1e-5
@@ -595,11 +915,9 @@ int validate(const DpcParams* p) {
   return DPC_OK;
 }
 
-// planes of an H x W slab that fit the LDS tile
+// planes of an H x W slab that fit the LDS tile of the generic kernels
 int planes_fit(const DpcParams* p) { return kLdsBudget / ((p->H * (p->W | 1)) * (int)sizeof(float)); }
-
 int slab_threads(const DpcParams* p) { return (long long)p->H * p->W >= 2048 ? kSlabThreads : 256; }
-
 int col_tiles(const DpcParams* p) { return (p->H * p->W + kColThreads - 1) / kColThreads; }
 
 template <class K>
@@ -617,6 +935,10 @@ RayHost ray_host(const DpcParams* p) {
 
 int launch_ok() { return hipGetLastError() == hipSuccess ? DPC_OK : DPC_ERR_LAUNCH; }
 
+Cells cells_view(const DpcParams* p, const void* cells) {
+  return Cells{static_cast<const uint8_t*>(cells), chunk_bytes(p->D), num_chunks(p->N)};
+}
+
 #define DPC_FOR_BUCKET(bucket, MACRO) \
   switch (bucket) {                   \
     case 0: MACRO(0); break;          \
@@ -630,11 +952,106 @@ int launch_ok() { return hipGetLastError() == hipSuccess ? DPC_OK : DPC_ERR_LAUN
     default: rc = DPC_ERR_TAPS;       \
   }
 
+// ---- slab kernel dispatch: specialised when H = W in {32, 64, 128} and the padded slab fits, else generic
+template <int GS, int ZS, int RB>
+int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
+                      uint64_t* mask, hipStream_t st) {
+  using Geo = SlabGeo<GS, RB>;
+  const size_t lds = Geo::slab_floats(ZS) * sizeof(float);
+  auto kern = k_splat_hw<GS, ZS, RB>;
+  int rc = set_lds(kern, lds);
+  if (rc != DPC_OK) return rc;
+  DPC_LAUNCH("k_splat_hw", kern, dim3((p->D + ZS - 1) / ZS, p->B), dim3(Geo::NT), lds, st, *p, cells,
+             make_taps<RB>(kxy, pxy, false), ZS, raw, Tbuf, mask);
+  return launch_ok();
+}
+
+template <int RB>
+int launch_splat(const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
+                 uint64_t* mask, hipStream_t st) {
+  if (p->H == p->W) {
+    if constexpr (RB <= 4) {
+      if (p->H == 32) return launch_splat_fast<32, 4, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, st);
+      if (p->H == 128) return launch_splat_fast<128, 2, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, st);
+    }
+    if constexpr (RB <= 10) {
+      if (p->H == 64) return launch_splat_fast<64, 8, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, st);
+    }
+  }
+  const int fit = planes_fit(p);
+  if (fit < 1) return DPC_ERR_LDS;
+  const int Zs = std::min(fit, std::max(1, (p->D + 7) / 8));
+  const size_t lds = (size_t)Zs * p->H * (p->W | 1) * sizeof(float);
+  auto kern = k_splat_hw<0, 0, RB>;
+  int rc = set_lds(kern, lds);
+  if (rc != DPC_OK) return rc;
+  DPC_LAUNCH("k_splat_hw", kern, dim3((p->D + Zs - 1) / Zs, p->B), dim3(slab_threads(p)), lds, st, *p, cells,
+             make_taps<RB>(kxy, pxy, false), Zs, raw, Tbuf, mask);
+  return launch_ok();
+}
+
+template <int GS, int ZS, int RB>
+int launch_gather_fast(const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
+                       const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask,
+                       const float* ds_part, int ntile, float* dpc, float* dsmall, hipStream_t st) {
+  using Geo = SlabGeo<GS, RB>;
+  const size_t lds = (((Geo::slab_floats(ZS + 1) + 3) / 4) * 4 + kRedFloats) * sizeof(float);
+  static_assert((((SlabGeo<GS, RB>::slab_floats(ZS + 1) + 3) / 4) * 4 + kRedFloats) * sizeof(float) <= kLdsLimit,
+                "backward slab does not fit LDS");
+  auto kern = k_gather_hw<GS, ZS, RB>;
+  int rc = set_lds(kern, lds);
+  if (rc != DPC_OK) return rc;
+  DPC_LAUNCH("k_gather_hw", kern, dim3((p->D + ZS - 1) / ZS, p->B), dim3(Geo::NT), lds, st, *p, cells, pc, q, t, f,
+             make_taps<RB>(kxy, pxy, true), ZS, dT, mask, ds_part, ntile, dpc, dsmall);
+  return launch_ok();
+}
+
+template <int RB>
+int launch_gather(const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
+                  const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part,
+                  int ntile, float* dpc, float* dsmall, hipStream_t st) {
+  if (p->H == p->W) {
+    if constexpr (RB <= 4) {
+      if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, st);
+      if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, st);
+      if (p->H == 64) return launch_gather_fast<64, 8, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, st);
+    } else if constexpr (RB <= 10) {
+      if (p->H == 64) return launch_gather_fast<64, 7, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, st);
+    }
+  }
+  const int fit = planes_fit(p);
+  if (fit < 2) return DPC_ERR_LDS;
+  const int Zs = std::min(fit - 1, std::max(1, (p->D + 7) / 8));
+  const size_t lds = ((size_t)(Zs + 1) * p->H * (p->W | 1) + kRedFloats) * sizeof(float);
+  auto kern = k_gather_hw<0, 0, RB>;
+  int rc = set_lds(kern, lds);
+  if (rc != DPC_OK) return rc;
+  DPC_LAUNCH("k_gather_hw", kern, dim3((p->D + Zs - 1) / Zs, p->B), dim3(slab_threads(p)), lds, st, *p, cells, pc, q, t, f,
+             make_taps<RB>(kxy, pxy, true), Zs, dT, mask, ds_part, ntile, dpc, dsmall);
+  return launch_ok();
+}
+
+int launch_locate(const DpcParams* p, int src, const void* pts, const float* q, const float* t, const float* f,
+                  float* tr_pc, void* cells, hipStream_t st) {
+  if (p->N == 0 || p->B == 0) return DPC_OK;
+  dim3 g(num_chunks(p->N), p->B), blk(kLocThreads);
+  uint8_t* out = static_cast<uint8_t*>(cells);
+  if (src == 0) DPC_LAUNCH("k_locate", k_locate<0>, g, blk, 0, st, *p, pts, q, t, f, tr_pc, out);
+  else if (src == 1) DPC_LAUNCH("k_locate", k_locate<1>, g, blk, 0, st, *p, pts, q, t, f, tr_pc, out);
+  else DPC_LAUNCH("k_locate", k_locate<2>, g, blk, 0, st, *p, pts, q, t, f, tr_pc, out);
+  return launch_ok();
+}
+
 }  // namespace
 
 extern "C" {
 
 size_t dpc_mask_words_per_plane(const DpcParams* p) { return p ? ((size_t)p->H * p->W + 63) / 64 : 0; }
+
+size_t dpc_cells_bytes(const DpcParams* p) {
+  if (validate(p) != DPC_OK) return 0;
+  return (size_t)p->B * num_chunks(p->N) * chunk_bytes(p->D);
+}
 
 size_t dpc_workspace_bytes(const DpcParams* p) {
   if (validate(p) != DPC_OK) return 0;
@@ -644,48 +1061,29 @@ size_t dpc_workspace_bytes(const DpcParams* p) {
 }
 
 int dpc_locate(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, float* tr_pc,
-               int32_t* cells, void* stream) {
+               void* cells, void* stream) {
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
   if (p->B == 0 || p->N == 0) return DPC_OK;
   if (!pc || !q || !cells) return DPC_ERR_NULL;
-  hipLaunchKernelGGL(k_locate<0>, dim3((p->N + 255) / 256, p->B), dim3(256), 0, (hipStream_t)stream, *p, (const void*)pc,
-                     q, t, f, tr_pc, reinterpret_cast<PointRec*>(cells));
-  return launch_ok();
+  return launch_locate(p, 0, pc, q, t, f, tr_pc, cells, (hipStream_t)stream);
 }
 
-// Stage-level splat (pointcloud2voxels3d_fast): locate (fp64) + the same slab kernel, raw grid only.
-int dpc_splat_fwd(const DpcParams* p, const void* tr, int tr_is_f64, int32_t* cells, float* vox, void* stream) {
+// Stage-level splat (pointcloud2voxels3d_fast): locate + the same slab kernel, raw grid only.
+int dpc_splat_fwd(const DpcParams* p, const void* tr, int tr_is_f64, void* cells, float* vox, void* stream) {
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
   if (!vox || (p->N > 0 && p->B > 0 && (!tr || !cells))) return DPC_ERR_NULL;
   if (p->B == 0) return DPC_OK;
-  const int fit = planes_fit(p);
-  if (fit < 1) return DPC_ERR_LDS;
   hipStream_t st = (hipStream_t)stream;
-  PointRec* recs = reinterpret_cast<PointRec*>(cells);
-  if (p->N > 0) {
-    dim3 gl((p->N + 255) / 256, p->B);
-    if (tr_is_f64)
-      hipLaunchKernelGGL(k_locate<2>, gl, dim3(256), 0, st, *p, tr, nullptr, nullptr, nullptr, nullptr, recs);
-    else
-      hipLaunchKernelGGL(k_locate<1>, gl, dim3(256), 0, st, *p, tr, nullptr, nullptr, nullptr, nullptr, recs);
-    if ((rc = launch_ok()) != DPC_OK) return rc;
-  }
-  const int Zs = std::min(fit, std::max(1, (p->D + 7) / 8));
-  const size_t lds = (size_t)Zs * p->H * (p->W | 1) * sizeof(float);
-  auto kern = k_splat_hw<0>;
-  if ((rc = set_lds(kern, lds)) != DPC_OK) return rc;
-  dim3 grid((p->D + Zs - 1) / Zs, p->B);
-  hipLaunchKernelGGL(kern, grid, dim3(slab_threads(p)), lds, st, *p, (const PointRec*)recs, TapsT<0>{{1.f}}, Zs, vox,
-                     nullptr, nullptr);
-  return launch_ok();
+  if ((rc = launch_locate(p, tr_is_f64 ? 2 : 1, tr, nullptr, nullptr, nullptr, nullptr, cells, st)) != DPC_OK) return rc;
+  const TapPlan none{0, 0, 0};
+  return launch_splat<0>(p, cells_view(p, cells), nullptr, none, vox, nullptr, nullptr, st);
 }
 
 int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
-                    const float* s, const float* host_kern_xy, const float* host_kern_z, float* tr_pc,
-                    int32_t* cells, float* raw, float* smoothed, uint64_t* mask, float* proj, void* workspace,
-                    void* stream) {
+                    const float* s, const float* host_kern_xy, const float* host_kern_z, float* tr_pc, void* cells,
+                    float* raw, float* smoothed, uint64_t* mask, float* proj, void* workspace, void* stream) {
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
   if (!q || !smoothed || !mask || !proj || !workspace) return DPC_ERR_NULL;
@@ -694,32 +1092,15 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
   if (p->B == 0) return DPC_OK;
   const TapPlan pxy = plan_taps(host_kern_xy, p->taps_xy), pz = plan_taps(host_kern_z, p->taps_z);
   if (pxy.bucket < 0) return DPC_ERR_TAPS;  // in-LDS passes need a radius bucket; caller composes the stage ops
-  const int fit = planes_fit(p);
-  if (fit < 1) return DPC_ERR_LDS;
-  const int Zs = std::min(fit, std::max(1, (p->D + 7) / 8));
-  const size_t lds = (size_t)Zs * p->H * (p->W | 1) * sizeof(float);
   float* Tbuf = static_cast<float*>(workspace);
   hipStream_t st = (hipStream_t)stream;
-  PointRec* recs = reinterpret_cast<PointRec*>(cells);
 
-  if (p->N > 0) {
-    DPC_LAUNCH("k_locate", k_locate<0>, dim3((p->N + 255) / 256, p->B), dim3(256), 0, st, *p, (const void*)pc, q, t, f,
-               tr_pc, recs);
-    if ((rc = launch_ok()) != DPC_OK) return rc;
-  }
-
-  dim3 gslab((p->D + Zs - 1) / Zs, p->B);
-#define LAUNCH_SPLAT(RB)                                                                                        \
-  {                                                                                                             \
-    auto kern = k_splat_hw<RB>;                                                                                 \
-    if ((rc = set_lds(kern, lds)) == DPC_OK)                                                                    \
-      DPC_LAUNCH("k_splat_hw", kern, gslab, dim3(slab_threads(p)), lds, st, *p, (const PointRec*)recs,          \
-                 make_taps<RB>(host_kern_xy, pxy, false), Zs, raw, Tbuf, mask);                                 \
-  }
+  if ((rc = launch_locate(p, 0, pc, q, t, f, tr_pc, cells, st)) != DPC_OK) return rc;
+  const Cells cv = cells_view(p, cells);
+#define LAUNCH_SPLAT(RB) rc = launch_splat<RB>(p, cv, host_kern_xy, pxy, raw, Tbuf, mask, st)
   DPC_FOR_BUCKET(pxy.bucket, LAUNCH_SPLAT)
 #undef LAUNCH_SPLAT
   if (rc != DPC_OK) return rc;
-  if ((rc = launch_ok()) != DPC_OK) return rc;
 
   dim3 gcol(col_tiles(p), p->B);
   const RayHost rh = ray_host(p);
@@ -734,15 +1115,14 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
   if (pz.bucket >= 0) { DPC_FOR_BUCKET(pz.bucket, LAUNCH_ZFWD) }
 #undef LAUNCH_ZFWD
   if (!done) {
-    rc = DPC_OK;
     DPC_LAUNCH("k_zcol_fwd", k_zcol_fwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s,
-                       make_taps_dyn(host_kern_z, p->taps_z, false), smoothed, proj);
+               make_taps_dyn(host_kern_z, p->taps_z, false), smoothed, proj);
   }
   return launch_ok();
 }
 
 int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
-                    const float* s, const float* host_kern_xy, const float* host_kern_z, const int32_t* cells,
+                    const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
                     const float* smoothed, const uint64_t* mask, const float* dproj, float* dpc, float* dsmall,
                     void* workspace, void* stream) {
   int rc = validate(p);
@@ -753,10 +1133,6 @@ int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const f
   if (p->B == 0) return DPC_OK;
   const TapPlan pxy = plan_taps(host_kern_xy, p->taps_xy), pz = plan_taps(host_kern_z, p->taps_z);
   if (pxy.bucket < 0) return DPC_ERR_TAPS;
-  const int fit = planes_fit(p);
-  if (fit < 2) return DPC_ERR_LDS;
-  const int Zs = std::min(fit - 1, std::max(1, (p->D + 7) / 8));
-  const size_t lds = ((size_t)(Zs + 1) * p->H * (p->W | 1) + kRedFloats) * sizeof(float);
   float* dT = static_cast<float*>(workspace);
   const size_t grid_bytes = (((size_t)p->B * p->D * p->H * p->W * sizeof(float) + 255) / 256) * 256;
   float* ds_part = reinterpret_cast<float*>(static_cast<char*>(workspace) + grid_bytes);
@@ -776,25 +1152,17 @@ int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const f
   if (pz.bucket >= 0) { DPC_FOR_BUCKET(pz.bucket, LAUNCH_ZBWD) }
 #undef LAUNCH_ZBWD
   if (!done) {
-    rc = DPC_OK;
     DPC_LAUNCH("k_zcol_bwd", k_zcol_bwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj,
-                       make_taps_dyn(host_kern_z, p->taps_z, true), dT, ds_part, dsmall);
+               make_taps_dyn(host_kern_z, p->taps_z, true), dT, ds_part, dsmall);
   }
   if ((rc = launch_ok()) != DPC_OK) return rc;
 
-  dim3 gslab((p->D + Zs - 1) / Zs, p->B);
-#define LAUNCH_GATHER(RB)                                                                                        \
-  {                                                                                                              \
-    auto kern = k_gather_hw<RB>;                                                                                 \
-    if ((rc = set_lds(kern, lds)) == DPC_OK)                                                                     \
-      DPC_LAUNCH("k_gather_hw", kern, gslab, dim3(slab_threads(p)), lds, st, *p, reinterpret_cast<const PointRec*>(cells), \
-                         pc, q, t, f, make_taps<RB>(host_kern_xy, pxy, true), Zs, dT, mask, ds_part, ntile, dpc,    \
-                         dsmall);                                                                                \
-  }
+  const Cells cv = cells_view(p, cells);
+#define LAUNCH_GATHER(RB) \
+  rc = launch_gather<RB>(p, cv, pc, q, t, f, host_kern_xy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, st)
   DPC_FOR_BUCKET(pxy.bucket, LAUNCH_GATHER)
 #undef LAUNCH_GATHER
-  if (rc != DPC_OK) return rc;
-  return launch_ok();
+  return rc;
 }
 
 }  // extern "C"

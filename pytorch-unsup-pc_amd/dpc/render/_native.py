@@ -12,9 +12,8 @@ import torch
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "csrc"))
 LIB_PATH = os.path.join(_CSRC, "libdpc_render.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 DPC_MAX_TAPS = 63
-DPC_CELL_INTS = 4
 DPC_SMALL_COLS = 12
 COL_DQ, COL_DS, COL_DT, COL_DF = 0, 4, 5, 8
 DPC_ERR_TAPS = -3
@@ -22,7 +21,7 @@ DPC_ERR_LDS = -4
 
 # every symbol include/dpc_render.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = (
-    "dpc_abi_version", "dpc_strerror", "dpc_mask_words_per_plane", "dpc_workspace_bytes", "dpc_locate",
+    "dpc_abi_version", "dpc_strerror", "dpc_mask_words_per_plane", "dpc_cells_bytes", "dpc_workspace_bytes", "dpc_locate",
     "dpc_project_fwd", "dpc_project_bwd", "dpc_transform_fwd", "dpc_transform_bwd",
     "dpc_splat_fwd", "dpc_splat_bwd", "dpc_smooth", "dpc_drc_fwd", "dpc_drc_bwd",
     "dpc_silhouette_loss", "dpc_profile_enable", "dpc_profile_disable", "dpc_profile_count", "dpc_profile_get",
@@ -61,6 +60,8 @@ def lib():
         L.dpc_strerror.argtypes = [ctypes.c_int]
         L.dpc_mask_words_per_plane.restype = ctypes.c_size_t
         L.dpc_mask_words_per_plane.argtypes = [pp]
+        L.dpc_cells_bytes.restype = ctypes.c_size_t
+        L.dpc_cells_bytes.argtypes = [pp]
         L.dpc_workspace_bytes.restype = ctypes.c_size_t
         L.dpc_workspace_bytes.argtypes = [pp]
         for name, nptr in (("dpc_project_fwd", 15), ("dpc_project_bwd", 15), ("dpc_transform_fwd", 6),

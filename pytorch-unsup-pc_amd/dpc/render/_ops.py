@@ -55,6 +55,33 @@ def _like_input(grad, meta):
     return None if grad is None or meta is None else grad.to(meta[0]).reshape(meta[1])
 
 
+def _new_cells(P, dev):
+    return torch.empty((max(N.lib().dpc_cells_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
+
+
+def decode_cells(cells, B, Npts, D):
+    """Test helper: binned point records -> (code [B,N] int32, frac [B,N,3] float32) in original point order."""
+    nblk = (Npts + 255) // 256
+    chunk = 256 * 20 + ((2 * (D + 2) + 15) // 16) * 16
+    raw = cells.cpu().numpy().reshape(B, nblk, chunk)
+    code = np.full((B, Npts), -2, dtype=np.int32)
+    frac = np.zeros((B, Npts, 3), dtype=np.float32)
+    for b in range(B):
+        for k in range(nblk):
+            n = min(256, Npts - 256 * k)
+            rec = raw[b, k, :256 * 16].view(np.int32).reshape(256, 4)[:n]
+            perm = raw[b, k, 256 * 16:256 * 20].view(np.int32)[:n]
+            offs = raw[b, k, 256 * 20:256 * 20 + 2 * (D + 2)].view(np.uint16)
+            assert offs[D + 1] == n and np.all(np.diff(offs.astype(np.int64)) >= 0)
+            bins = np.where(rec[:, 0] < 0, D, rec[:, 0] >> 20)
+            assert np.array_equal(np.sort(bins), bins), "records are not sorted by z bin"
+            assert np.array_equal(np.searchsorted(bins, np.arange(D + 2)), offs), "bin offsets do not match the records"
+            code[b, perm] = rec[:, 0]
+            frac[b, perm] = rec[:, 1:].view(np.float32)
+    assert (code != -2).all(), "some points are missing from the bins"
+    return code, frac
+
+
 def locate_points(pc, q, t, f, geom):
     """First launch of the fused forward alone: (tr_pc [B,N,3] fp32, cells [B,N,4] int32 point records)."""
     dev = N.require_device(pc, q, t, f)
@@ -62,7 +89,7 @@ def locate_points(pc, q, t, f, geom):
     B, Npts = pc32.shape[0], pc32.shape[1]
     P = geom.params(B, Npts)
     tr = torch.empty_like(pc32)
-    cells = torch.empty((B, Npts, N.DPC_CELL_INTS), dtype=torch.int32, device=dev)
+    cells = _new_cells(P, dev)
     with torch.cuda.device(dev):
         rc = N.lib().dpc_locate(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(tr), N.ptr(cells),
                                 N.stream_ptr(dev))
@@ -90,7 +117,7 @@ class ProjectFused(torch.autograd.Function):
         wpp = L.dpc_mask_words_per_plane(ctypes.byref(P))
         smoothed = torch.empty((B, geom.D, geom.H, geom.W), dtype=torch.float32, device=dev)
         mask = torch.empty((B, geom.D, wpp), dtype=torch.int64, device=dev)
-        cells = torch.empty((B, Npts, N.DPC_CELL_INTS), dtype=torch.int32, device=dev)
+        cells = _new_cells(P, dev)
         proj = torch.empty((B, geom.H, geom.W, 1), dtype=torch.float32, device=dev)
         ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
         kxy, kz = geom.kern_ptrs()
@@ -186,7 +213,7 @@ class Splat(torch.autograd.Function):
         trc = tr.detach().contiguous() if is64 else _f32(tr)
         P = geom.params(trc.shape[0], trc.shape[1])
         vox = torch.empty((trc.shape[0], geom.D, geom.H, geom.W), dtype=torch.float32, device=dev)
-        cells = torch.empty((trc.shape[0], trc.shape[1], N.DPC_CELL_INTS), dtype=torch.int32, device=dev)
+        cells = _new_cells(P, dev)
         with torch.cuda.device(dev):
             rc = N.lib().dpc_splat_fwd(ctypes.byref(P), N.ptr(trc), int(is64), N.ptr(cells), N.ptr(vox), N.stream_ptr(dev))
         N.check(rc, "dpc_splat_fwd")

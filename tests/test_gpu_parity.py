@@ -96,7 +96,7 @@ def oracle_records(O, cfg, pc, q, t, f):
 def test_locate_bit_exact(R, O, with_t, with_f):
     """Integer/bit-level parity of the first launch: cell indices, validity and the encoded fractional
     weights equal those derived from the reference's (oracle's) fp64 transform, for every point."""
-    from dpc.render._ops import locate_points
+    from dpc.render._ops import locate_points, decode_cells
     from dpc.render import _geometry
 
     cfg = O.Cfg(vox_size=64)
@@ -104,9 +104,9 @@ def test_locate_bit_exact(R, O, with_t, with_f):
     pc = pc * 1.3  # push ~10% of the points out of bounds
     tr_ref, code, enc = oracle_records(O, cfg, pc, q, t, f)
     tr, cells = locate_points(dev(pc), dev(q), dev(t), dev(f), _geometry(cfg))
-    cells = cells.cpu().numpy()
-    assert np.array_equal(cells[..., 0], code), "cell index / validity differs for %d points" % (cells[..., 0] != code).sum()
-    assert np.array_equal(cells[..., 1:].view(np.float32), enc), "encoded fractions differ"
+    got_code, got_enc = decode_cells(cells, 8, 8000, 64)  # also checks the per-chunk z sort and bin offsets
+    assert np.array_equal(got_code, code), "cell index / validity differs for %d points" % (got_code != code).sum()
+    assert np.array_equal(got_enc, enc), "encoded fractions differ"
     assert np.array_equal(tr.cpu().numpy(), tr_ref.astype(np.float32)), "tr_pc is not the fp32 rounding of the reference's"
     assert 0.02 < (code < 0).mean() < 0.5
 
