@@ -31,6 +31,14 @@
 #include "dpc_common.h"
 #include "dpc_profile.h"
 
+#ifdef DPC_ABLATE
+__device__ int g_dpc_ablate = 0;  // diagnostic builds only: bit0 skip zero-fill, bit1 skip atomics, bit2 skip W, bit3 skip H
+extern "C" int dpc_debug_set_ablate(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_dpc_ablate), &v, sizeof(int)) == hipSuccess ? 0 : -5; }
+#define DPC_ABL(bit) (g_dpc_ablate & (1 << (bit)))
+#else
+#define DPC_ABL(bit) 0
+#endif
+
 namespace {
 
 constexpr int kSlabThreads = 1024;
@@ -228,23 +236,32 @@ __device__ inline void hpass(float* slab, int nz, int H, int W, int WP, const Ta
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int GS, int RB>
+template <int GS, int RB, int NT_, int LW_, int LH_>
 struct SlabGeo {
   static constexpr int PAD = RB <= 4 ? 4 : ((RB + 3) / 4) * 4;
   static constexpr int WP = GS + PAD;
   static constexpr int PLANE = GS * WP;
-  static constexpr int LW = 32, NSEGW = GS / LW, LWIN = LW + 2 * PAD;   // W-pass
-  static constexpr int LH = 16, NSEGH = GS / LH, XP = GS / 2, HWIN = LH + 2 * RB;  // H-pass
-  static constexpr int NT = GS >= 64 ? 1024 : 256;
+  static constexpr int LW = LW_, NSEGW = GS / LW, LWIN = LW + 2 * PAD;              // W-pass
+  static constexpr int LH = LH_, NSEGH = GS / LH, XP = GS / 2, HWIN = LH + 2 * RB;  // H-pass
+  static constexpr int NT = NT_;
   __host__ __device__ static constexpr size_t slab_floats(int planes) { return (size_t)planes * PLANE + PAD; }
   __device__ static int at(int z, int y, int x) { return (z * GS + y) * WP + PAD + x; }
 };
+// forward: ZS planes, 16 voxels per thread, short segments so that every thread owns exactly one W and one H item
+template <int GS, int ZS, int RB>
+using FwdGeo = SlabGeo<GS, RB, ZS * GS * GS / 16, 16, 8>;
+// backward: ZS+1 planes (halo), long segments
+template <int GS, int RB>
+using BwdGeo = SlabGeo<GS, RB, (GS >= 64 ? 1024 : 256), 32, 16>;
+
+constexpr float kFixScale = 17592186044416.0f;          // 2^44: splat weights accumulate as 64-bit fixed point
+constexpr float kFixInv = 1.0f / 17592186044416.0f;
+constexpr unsigned long long kFixOne = 1ull << 44;
 
 // In-place W-pass over NPL planes.  MASK: 0 none, 1 emit the clamp mask from the raw values (forward),
 // 2 multiply the outputs by the stored mask bits (backward).  mask32 points at this slab's first plane.
-template <int GS, int RB, int NPL, bool CLAMP1, int MASK>
+template <class Geo, int GS, int RB, int NPL, bool CLAMP1, int MASK>
 __device__ inline void wpass_fast(float* slab, const TapsT<RB>& taps, uint32_t* mask32, int planes_present) {
-  using Geo = SlabGeo<GS, RB>;
   constexpr int ROWS = NPL * GS, ITEMS = ROWS * Geo::NSEGW, IPT = (ITEMS + Geo::NT - 1) / Geo::NT;
   float v[IPT][Geo::LWIN];
 #pragma unroll
@@ -268,12 +285,9 @@ __device__ inline void wpass_fast(float* slab, const TapsT<RB>& taps, uint32_t* 
       const int row = item % ROWS, seg = item / ROWS;
       const int z = row / GS;
       uint32_t bits = 0xffffffffu;
-      if (MASK == 1) {
-        bits = 0u;
-#pragma unroll
-        for (int j = 0; j < Geo::LW; ++j) bits |= (v[it][Geo::PAD + j] <= 1.0f ? 1u : 0u) << j;
-        if (z < planes_present) mask32[(size_t)row * Geo::NSEGW + seg] = bits;
-      } else if (MASK == 2) {
+      static_assert(MASK != 1, "the forward emits its mask from the fixed-point accumulators");
+      if (MASK == 2) {  // LW outputs starting at x = seg*LW: bits of the row's mask words
+        static_assert(MASK != 2 || Geo::LW == 32, "mask word addressing assumes 32-output segments");
         bits = z < planes_present ? mask32[(size_t)row * Geo::NSEGW + seg] : 0u;
       }
       if (CLAMP1) {
@@ -303,9 +317,8 @@ __device__ inline void wpass_fast(float* slab, const TapsT<RB>& taps, uint32_t* 
 
 // H-pass over NPL planes, two adjacent columns per thread.  store(z, y, x_even, pair) consumes the results;
 // INPLACE inserts the barrier between the window reads and the stores.
-template <int GS, int RB, int NPL, bool INPLACE, class Store>
+template <class Geo, int GS, int RB, int NPL, bool INPLACE, class Store>
 __device__ inline void hpass_fast(const float* slab, const TapsT<RB>& taps, Store store) {
-  using Geo = SlabGeo<GS, RB>;
   constexpr int ITEMS = NPL * Geo::XP * Geo::NSEGH, IPT = (ITEMS + Geo::NT - 1) / Geo::NT;
   f32x2 v[IPT][Geo::HWIN];
 #pragma unroll
@@ -314,14 +327,13 @@ __device__ inline void hpass_fast(const float* slab, const TapsT<RB>& taps, Stor
     if (item < ITEMS) {
       const int xp = item % Geo::XP, rest = item / Geo::XP;
       const int z = rest % NPL, seg = rest / NPL;
-      const bool lo = seg == 0, hi = seg == Geo::NSEGH - 1;
       const float* col = slab + Geo::at(z, 0, 2 * xp);
       const int y0 = seg * Geo::LH - RB;
 #pragma unroll
       for (int i = 0; i < Geo::HWIN; ++i) {
         // only the first/last RB rows of a window can fall outside the plane (zero padding): clamp the
         // address, then zero the value
-        const bool out = (i < RB && lo) || (i >= Geo::LH + RB && hi);
+        const bool out = (i < RB && y0 + i < 0) || (i >= Geo::LH + RB && y0 + i >= GS);
         const int y = out ? 0 : y0 + i;
         f32x2 q = *reinterpret_cast<const f32x2*>(col + y * Geo::WP);
         if (out) q = f32x2{0.f, 0.f};
@@ -367,10 +379,17 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
   const size_t HW = (size_t)H * W;
 
   if constexpr (GS > 0) {
-    using Geo = SlabGeo<GS, RB>;
+    // Splat accumulation in 64-bit fixed point (2^-44): integer LDS atomics run ~9x faster than ds_add_f32 on
+    // gfx950 (measured), the sums are exact to 6e-14 per contribution and independent of arrival order.
+    using Geo = FwdGeo<GS, ZS, RB>;
+    constexpr int VOX = ZS * GS * GS, VPT = VOX / Geo::NT;  // voxels per thread in the conversion pass
+    static_assert(VOX % Geo::NT == 0 && Geo::NT % 64 == 0 && (GS * GS) % 64 == 0, "slab shape");
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(slab);
     f32x4* s4 = reinterpret_cast<f32x4*>(slab);
-    for (int i = tid; i < (int)(Geo::slab_floats(ZS) / 4); i += Geo::NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (!DPC_ABL(0))
+    for (int i = tid; i < VOX / 2; i += Geo::NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
+    if (!DPC_ABL(4))
     for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, [&](const PointRec& rec, int) {
       const Cell c = cell_from_record(rec);
 #pragma unroll
@@ -383,41 +402,55 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
             if (c.ix + e >= GS) continue;
-            atomicAdd(&slab[Geo::at(zz, c.iy + j, c.ix + e)], c.wz[k] * c.wy[j] * c.wx[e]);  // ds_add_f32
+            const float w = c.wz[k] * c.wy[j] * c.wx[e];
+            atomicAdd(&acc[(zz * GS + c.iy + j) * GS + c.ix + e], (unsigned long long)(w * kFixScale));  // ds_add_u64
           }
         }
       }
     });
     __syncthreads();
-    if (raw != nullptr) {  // stage-level splat: the raw grid itself
-      float* dst = raw + ((size_t)b * D + z0) * HW;
-      for (int i = tid; i < nz * GS * (GS / 4); i += Geo::NT) {
-        const int x4 = i % (GS / 4), zy = i / (GS / 4);
-        *reinterpret_cast<f32x4*>(dst + (size_t)zy * GS + 4 * x4) =
-            *reinterpret_cast<const f32x4*>(slab + zy * Geo::WP + Geo::PAD + 4 * x4);
-      }
+    // accumulators -> fp32 (registers), clamp mask straight from the integers (raw <= 1  <=>  acc <= 2^44)
+    float val[VPT];
+    const size_t wpp = (HW + 63) / 64;
+    unsigned long long* mask_out = mask ? reinterpret_cast<unsigned long long*>(mask) + ((size_t)b * D + z0) * wpp : nullptr;
+    float* Tout = Tbuf ? Tbuf + ((size_t)b * D + z0) * HW : nullptr;
+#pragma unroll
+    for (int n = 0; n < VPT; ++n) {
+      const int i = tid + n * Geo::NT;  // lanes <-> consecutive x
+      const unsigned long long a = acc[i];
+      const unsigned long long bits = __ballot(a <= kFixOne);
+      const bool present = i < nz * GS * GS;
+      if (mask_out != nullptr && present && (tid & 63) == 0) mask_out[i >> 6] = bits;
+      const float v = (float)a * kFixInv;
+      if (raw != nullptr && present) raw[((size_t)b * D + z0) * HW + i] = v;
+      val[n] = fminf(v, 1.0f);
     }
     if (Tbuf == nullptr) return;
-    uint32_t* mask32 = reinterpret_cast<uint32_t*>(mask + ((size_t)b * D + z0) * ((HW + 63) / 64));
-    float* Tout = Tbuf + ((size_t)b * D + z0) * HW;
-    if constexpr (RB == 0) {
-      // no smoothing (centre tap 1) or a kernel trimmed to its centre tap: T = w0^2 clamp(raw,0,1) + the mask
+    if constexpr (RB == 0) {  // no smoothing (centre tap 1) or a kernel trimmed to its centre tap
       const float w2 = taps.w[0] * taps.w[0];
-      const int lane = tid & 63;
-      for (int i = tid; i < ZS * GS * GS; i += Geo::NT) {
-        const int x = i % GS, zy = i / GS, z = zy / GS;
-        const float vraw = slab[zy * Geo::WP + Geo::PAD + x];
-        const unsigned long long bits = __ballot(vraw <= 1.0f);
-        if (z < nz) {
-          if (lane == 0) reinterpret_cast<unsigned long long*>(mask32)[i >> 6] = bits;
-          Tout[i] = w2 * fminf(vraw, 1.0f);
-        }
+#pragma unroll
+      for (int n = 0; n < VPT; ++n) {
+        const int i = tid + n * Geo::NT;
+        if (i < nz * GS * GS) Tout[i] = w2 * val[n];
       }
       return;
     } else {
-      wpass_fast<GS, RB, ZS, true, 1>(slab, taps, mask32, nz);
-      hpass_fast<GS, RB, ZS, false>(slab, taps, [&](int z, int y, int x, f32x2 val) {
-        if (z < nz) *reinterpret_cast<f32x2*>(Tout + ((size_t)z * GS + y) * GS + x) = val;
+      __syncthreads();  // every accumulator has been read: the same LDS now takes the padded fp32 slab
+#pragma unroll
+      for (int n = 0; n < VPT; ++n) {
+        const int i = tid + n * Geo::NT;
+        slab[(i / GS) * Geo::WP + Geo::PAD + (i % GS)] = val[n];
+      }
+      for (int i = tid; i < (ZS * GS + 1) * (Geo::PAD / 4); i += Geo::NT) {  // zero row pads (and the tail pad)
+        const int p4 = i % (Geo::PAD / 4), row = i / (Geo::PAD / 4);
+        *reinterpret_cast<f32x4*>(slab + row * Geo::WP + 4 * p4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      __syncthreads();
+      if (!DPC_ABL(2))
+      wpass_fast<Geo, GS, RB, ZS, false, 0>(slab, taps, nullptr, nz);
+      if (!DPC_ABL(3))
+      hpass_fast<Geo, GS, RB, ZS, false>(slab, taps, [&](int z, int y, int x, f32x2 v2) {
+        if (z < nz) *reinterpret_cast<f32x2*>(Tout + ((size_t)z * GS + y) * GS + x) = v2;
       });
     }
   } else {
@@ -725,7 +758,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   float* red;
 
   if constexpr (GS > 0) {
-    using Geo = SlabGeo<GS, RB>;
+    using Geo = BwdGeo<GS, RB>;
     constexpr int NPL = ZS + 1;
     red = slab + ((Geo::slab_floats(NPL) + 3) / 4) * 4;
     // planes -> LDS (16-byte global loads, 16-byte LDS stores); absent planes and the row pads are zeroed
@@ -751,10 +784,10 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
       }
       __syncthreads();
     } else {
-      hpass_fast<GS, RB, NPL, true>(slab, taps_adj, [&](int z, int y, int x, f32x2 val) {
+      hpass_fast<Geo, GS, RB, NPL, true>(slab, taps_adj, [&](int z, int y, int x, f32x2 val) {
         *reinterpret_cast<f32x2*>(slab + Geo::at(z, y, x)) = val;
       });
-      wpass_fast<GS, RB, NPL, false, 2>(slab, taps_adj, const_cast<uint32_t*>(mask32), nzp);
+      wpass_fast<Geo, GS, RB, NPL, false, 2>(slab, taps_adj, const_cast<uint32_t*>(mask32), nzp);
     }
   } else {
     const int WP = odd_stride(W);
@@ -791,7 +824,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   const float* cloud = pc + (size_t)b * N * 3;
   float* dcloud = dpc + (size_t)b * N * 3;
   auto corner = [&](int zz, int yy, int xx) -> float {
-    if constexpr (GS > 0) return slab[SlabGeo<GS, RB>::at(zz, yy, xx)];
+    if constexpr (GS > 0) return slab[BwdGeo<GS, RB>::at(zz, yy, xx)];
     else return slab[(zz * H + yy) * odd_stride(W) + xx];
   };
   for_each_record(cells, b, z0, min(z0 + Zs, D), [&](const PointRec& rec, int i) {
@@ -952,12 +985,18 @@ Cells cells_view(const DpcParams* p, const void* cells) {
     default: rc = DPC_ERR_TAPS;       \
   }
 
+#ifndef DPC_FWD_ZS64
+#define DPC_FWD_ZS64 4
+#endif
+constexpr int kFwdZs64 = DPC_FWD_ZS64;  // planes per forward slab at G = 64 (4 -> 1 workgroup/CU, 2 -> 2 workgroups/CU)
+
 // ---- slab kernel dispatch: specialised when H = W in {32, 64, 128} and the padded slab fits, else generic
 template <int GS, int ZS, int RB>
 int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
                       uint64_t* mask, hipStream_t st) {
-  using Geo = SlabGeo<GS, RB>;
-  const size_t lds = Geo::slab_floats(ZS) * sizeof(float);
+  using Geo = FwdGeo<GS, ZS, RB>;
+  constexpr size_t lds = std::max((size_t)ZS * GS * GS * sizeof(unsigned long long), Geo::slab_floats(ZS) * sizeof(float));
+  static_assert(lds <= kLdsLimit, "forward slab does not fit LDS");
   auto kern = k_splat_hw<GS, ZS, RB>;
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
@@ -972,10 +1011,10 @@ int launch_splat(const DpcParams* p, Cells cells, const float* kxy, const TapPla
   if (p->H == p->W) {
     if constexpr (RB <= 4) {
       if (p->H == 32) return launch_splat_fast<32, 4, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, st);
-      if (p->H == 128) return launch_splat_fast<128, 2, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, st);
+      if (p->H == 128) return launch_splat_fast<128, 1, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, st);
     }
     if constexpr (RB <= 10) {
-      if (p->H == 64) return launch_splat_fast<64, 8, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, st);
+      if (p->H == 64) return launch_splat_fast<64, kFwdZs64, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, st);
     }
   }
   const int fit = planes_fit(p);
@@ -994,10 +1033,9 @@ template <int GS, int ZS, int RB>
 int launch_gather_fast(const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
                        const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask,
                        const float* ds_part, int ntile, float* dpc, float* dsmall, hipStream_t st) {
-  using Geo = SlabGeo<GS, RB>;
-  const size_t lds = (((Geo::slab_floats(ZS + 1) + 3) / 4) * 4 + kRedFloats) * sizeof(float);
-  static_assert((((SlabGeo<GS, RB>::slab_floats(ZS + 1) + 3) / 4) * 4 + kRedFloats) * sizeof(float) <= kLdsLimit,
-                "backward slab does not fit LDS");
+  using Geo = BwdGeo<GS, RB>;
+  constexpr size_t lds = (((Geo::slab_floats(ZS + 1) + 3) / 4) * 4 + kRedFloats) * sizeof(float);
+  static_assert(lds <= kLdsLimit, "backward slab does not fit LDS");
   auto kern = k_gather_hw<GS, ZS, RB>;
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
