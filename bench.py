@@ -114,8 +114,8 @@ def main():
 
     def step():
         pc.grad = q.grad = s.grad = None
-        proj = R.pointcloud_project_fast(cfg, pc, q, None, None, kern, scaling_factor=s)["proj"]
-        loss, _ = R.silhouette_loss(proj, gt)  # sum((proj-gt)^2)/B fused with its gradient
+        # projection + sum((proj-gt)^2)/B in one autograd node (loss folded into the ray-march kernels)
+        loss, _, _ = R.pointcloud_project_loss(cfg, pc, q, None, None, kern, scaling_factor=s, gt=gt)
         loss.backward()
         return loss
 

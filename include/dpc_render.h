@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DPC_ABI_VERSION 3
+#define DPC_ABI_VERSION 4
 #define DPC_MAX_TAPS 63 /* longest 1-D smoothing kernel accepted (pc_gauss_kernel_size) */
 
 enum {
@@ -86,7 +86,7 @@ size_t dpc_workspace_bytes(const DpcParams* p);
  * Fused hot path: replaces pointcloud_project_fast (dpc/util/point_cloud_to.py:191-263) =
  * pc_perspective_transform (:118-178) -> pointcloud2voxels3d_fast (:10-87) -> clamp (:201) ->
  * smoothen_voxels3d (:90-103) -> scale+clamp (:218-222) -> drc_projection (dpc/util/drc.py:114-129) ->
- * flip (:242), in three launches (locate + z-sort points -> splat+W/H passes in LDS -> z column pass + DRC).
+ * flip (:242), in three launches (locate + z-sort points -> splat + W/H passes in LDS -> z column pass + DRC).
  *   pc [B,N,3], q [B,4], t [B,3]|NULL, f [B,1]|NULL, s [B,1]|NULL, host_kern_xy[taps_xy], host_kern_z[taps_z]
  *   (HOST pointers: the tap weights travel as kernel arguments)
  * outputs
@@ -97,11 +97,12 @@ size_t dpc_workspace_bytes(const DpcParams* p);
  *            voxels = s ? clamp(s*smoothed,0,1) : smoothed)
  *   mask     [B,D,words] uint64 clamp mask (saved for backward)
  *   proj     [B,H,W] silhouette, rows already flipped
+ *   trans    [B,H,W] per-ray transmittance prod(1-y) (ray order, not flipped) | NULL; saves the backward a pass
  * ------------------------------------------------------------------------------------------------- */
 int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                     const float* s, const float* host_kern_xy, const float* host_kern_z, float* tr_pc,
-                    void* cells, float* raw, float* smoothed, uint64_t* mask, float* proj, void* workspace,
-                    void* stream);
+                    void* cells, float* raw, float* smoothed, uint64_t* mask, float* proj, float* trans,
+                    void* workspace, void* stream);
 
 /* Hand-written backward of the chain above (the reference relies on autograd).
  *   dproj [B,H,W] gradient w.r.t. the (flipped) silhouette
@@ -111,8 +112,26 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
  *          the matching input was given); fully overwritten, needs no zeroing by the caller. */
 int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                     const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
-                    const float* smoothed, const uint64_t* mask, const float* dproj, float* dpc, float* dsmall,
-                    void* workspace, void* stream);
+                    const float* smoothed, const uint64_t* mask, const float* trans /* from fwd, or NULL */,
+                    const float* dproj, float* dpc, float* dsmall, void* workspace, void* stream);
+
+/* The same chain with the caller's silhouette loss fused in: add_proj_loss /
+ * proj_loss_pose_candidates (dpc/models/model_pc_to.py:339-385, 410-440).  Cloud b is pose candidate b % K of
+ * sample b / K; gt [B/K, H, W] is the mask already pooled to the silhouette size.  The ray-march kernel
+ * accumulates each cloud's sum of squared differences, a one-block finalize picks argmin over K (first minimum)
+ * and writes loss = sum_s min_k sse / S.  In the backward dproj = 2 (proj - gt) / S * dloss is formed on the fly
+ * (never stored) and losing candidates skip all work -- their gradients are exact zeros.
+ *   fwd outputs: proj [B,H,W], trans [B,H,W], sse [B], loss [1], winner [B/K] int32 (+ tr_pc|NULL, cells, smoothed, mask)
+ *   bwd inputs : dloss = device scalar arriving at `loss` (NULL = 1) */
+int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                         const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt,
+                         int num_candidates, float* tr_pc, void* cells, float* smoothed, uint64_t* mask, float* proj,
+                         float* trans, float* sse, float* loss, int32_t* winner, void* workspace, void* stream);
+int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                         const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
+                         const float* smoothed, const uint64_t* mask, const float* proj, const float* trans,
+                         const float* gt, int num_candidates, const int32_t* winner, const float* dloss, float* dpc,
+                         float* dsmall, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Stage-level entry points (one per reference function), used for the sub-stage API and to cross-check the

@@ -300,8 +300,11 @@ __device__ inline float wave_sum(float v) {
 }
 
 // Sum NV per-thread values over the block; result valid in thread 0.  red must hold NV * (blockDim/64) floats.
+// Wave shuffles, then lanes 0..NV-1 of wave 0 each add one value's per-wave partials (independent LDS reads
+// that pipeline), then thread 0 collects the NV results with shuffles -- no serial chain of LDS latencies.
 template <int NV>
 __device__ inline void block_sum(float (&vals)[NV], float* red) {
+  static_assert(NV <= DPC_WAVE, "one lane per value");
   const int lane = threadIdx.x & (DPC_WAVE - 1), wave = threadIdx.x / DPC_WAVE, nw = (blockDim.x + DPC_WAVE - 1) / DPC_WAVE;
 #pragma unroll
   for (int i = 0; i < NV; ++i) vals[i] = wave_sum(vals[i]);
@@ -310,12 +313,11 @@ __device__ inline void block_sum(float (&vals)[NV], float* red) {
     for (int i = 0; i < NV; ++i) red[wave * NV + i] = vals[i];
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (wave == 0) {
+    float s = 0.f;
+    if (lane < NV)
+      for (int k = 0; k < nw; ++k) s += red[k * NV + lane];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      float s = 0.f;
-      for (int k = 0; k < nw; ++k) s += red[k * NV + i];
-      vals[i] = s;
-    }
+    for (int i = 0; i < NV; ++i) vals[i] = __shfl(s, i, DPC_WAVE);
   }
 }

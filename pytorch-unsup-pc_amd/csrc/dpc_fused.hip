@@ -369,8 +369,9 @@ __device__ inline void hpass_fast(const float* slab, const TapsT<RB>& taps, Stor
 template <int GS, int ZS, int RB>
 __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells cells, TapsT<RB> taps, int zs_rt,
                                                            float* __restrict__ raw, float* __restrict__ Tbuf,
-                                                           uint64_t* __restrict__ mask) {
+                                                           uint64_t* __restrict__ mask, float* __restrict__ sse) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
+  if (sse != nullptr && blockIdx.x == 0 && threadIdx.x == 0) sse[blockIdx.y] = 0.f;  // k_zcol_fwd accumulates into it
   const int D = P.D, H = P.H, W = P.W;
   const int Zs = GS ? ZS : zs_rt;
   const int b = blockIdx.y, z0 = blockIdx.x * Zs;
@@ -421,7 +422,8 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
       const unsigned long long bits = __ballot(a <= kFixOne);
       const bool present = i < nz * GS * GS;
       if (mask_out != nullptr && present && (tid & 63) == 0) mask_out[i >> 6] = bits;
-      const float v = (float)a * kFixInv;
+      // a < 2^56: hi < 2^24 converts exactly, lo rounds once, the fma rounds once more (<= 1 ulp overall)
+      const float v = fmaf((float)(unsigned)(a >> 32), 0x1p-12f, (float)(unsigned)a * kFixInv);
       if (raw != nullptr && present) raw[((size_t)b * D + z0) * HW + i] = v;
       val[n] = fminf(v, 1.0f);
     }
@@ -556,78 +558,164 @@ __device__ inline float drc_voxel_bwd(const RayConst& r, float v2, float g, floa
   return m ? r.s * dv3 : 0.f;
 }
 
+// Fused silhouette loss (dpc/models/model_pc_to.py:339-385, 410-440): cloud b is candidate b % K of sample b / K.
+//   forward : sse[b] += sum_pixels (gt - proj)^2            (k_zcol_fwd epilogue; zeroed by k_splat_hw)
+//   finalize: winner[s] = argmin_k sse[s*K+k], loss = sum_s min_k sse / S      (k_loss_finalize)
+//   backward: dproj = winner ? 2 (proj - gt) / S * dloss : 0, formed on the fly; losing candidates do nothing
+struct LossArgs {
+  const float* gt;      // [S, H*W] in image orientation (rows already flipped like proj); nullptr = no fused loss
+  float* sse;           // [B]
+  const int* winner;    // [S] (backward)
+  const float* dloss;   // device scalar, gradient arriving at the loss (backward); nullptr = 1
+  int K;
+  float inv_S;
+};
+
+__global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ sse, int S, int K, float inv_S,
+                                                       float* __restrict__ loss, int* __restrict__ winner) {
+  __shared__ float red[256 / DPC_WAVE];
+  float acc = 0.f;
+  for (int smp = threadIdx.x; smp < S; smp += blockDim.x) {
+    float best = sse[(size_t)smp * K];
+    int bk = 0;
+    for (int k = 1; k < K; ++k) {
+      const float v = sse[(size_t)smp * K + k];
+      if (v < best) { best = v; bk = k; }  // first minimum wins, like torch.argmin
+    }
+    winner[smp] = bk;
+    acc += best;
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < 256 / DPC_WAVE; ++i) tot += red[i];
+    *loss = tot * inv_S;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Forward 2: D-pass + scale/clamp + DRC silhouette, whole z column in registers.   grid (ceil(HW/256), B)
 // ------------------------------------------------------------------------------------------------------
+// Epilogue shared by the forward column kernels: silhouette (row flip folded into the index), saved ray
+// transmittance, fused loss partial.
+__device__ inline void zcol_fwd_epilogue(const DpcParams& P, const RayConst& rc, int b, int ray, bool live, double trans,
+                                         float y0, float* __restrict__ proj, float* __restrict__ trans_out,
+                                         const LossArgs& la) {
+  const int HW = P.H * P.W;
+  float sq = 0.f;
+  if (live) {
+    const int yrow = ray / P.W, x = ray - yrow * P.W;
+    const int pix = (P.H - 1 - yrow) * P.W + x;
+    const float pr = (float)(1.0 - trans + (double)rc.em1 * (double)y0);
+    proj[(size_t)b * HW + pix] = pr;
+    if (trans_out != nullptr) trans_out[(size_t)b * HW + ray] = (float)trans;
+    if (la.gt != nullptr) {
+      const float d = la.gt[(size_t)(b / la.K) * HW + pix] - pr;
+      sq = d * d;
+    }
+  }
+  if (la.gt != nullptr) {  // block-uniform
+    __shared__ float red[kColThreads / DPC_WAVE];
+    sq = wave_sum(sq);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float tot = 0.f;
+      for (int i = 0; i < kColThreads / DPC_WAVE; ++i) tot += red[i];
+      atomicAdd(la.sse + b, tot);
+    }
+  }
+}
+
 template <int DD, int RB>
 __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_fwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf,
                                                           const float* __restrict__ s, TapsT<RB> taps,
-                                                          float* __restrict__ smoothed, float* __restrict__ proj) {
+                                                          float* __restrict__ smoothed, float* __restrict__ proj,
+                                                          float* __restrict__ trans_out, LossArgs la) {
   const int HW = P.H * P.W;
   const int b = blockIdx.y, ray = blockIdx.x * kColThreads + threadIdx.x;
-  if (ray >= HW) return;
+  const bool live = ray < HW;
   const RayConst rc = ray_const(rh, s, b);
-  const float* col = Tbuf + (size_t)b * DD * HW + ray;
-  float* out = smoothed + (size_t)b * DD * HW + ray;
-  float c[DD];
-#pragma unroll
-  for (int z = 0; z < DD; ++z) c[z] = col[(size_t)z * HW];
   double trans = 1.0;
   float y0 = 0.f;
+  if (live) {
+    const float* col = Tbuf + (size_t)b * DD * HW + ray;
+    float* out = smoothed + (size_t)b * DD * HW + ray;
+    float c[DD];
 #pragma unroll
-  for (int z = 0; z < DD; ++z) {
-    float v2 = 0.f;
+    for (int z = 0; z < DD; ++z) c[z] = col[(size_t)z * HW];
 #pragma unroll
-    for (int k = 0; k < 2 * RB + 1; ++k) {
-      const int zz = z + k - RB;
-      if (zz >= 0 && zz < DD) v2 = fmaf(taps.w[k], c[zz], v2);
+    for (int z = 0; z < DD; ++z) {
+      float v2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2 * RB + 1; ++k) {
+        const int zz = z + k - RB;
+        if (zz >= 0 && zz < DD) v2 = fmaf(taps.w[k], c[zz], v2);
+      }
+      out[(size_t)z * HW] = v2;
+      const float y = drc_clamp(rc, occupancy(rc, v2));
+      if (z == 0) y0 = y;
+      trans *= 1.0 - (double)y;
     }
-    out[(size_t)z * HW] = v2;
-    const float y = drc_clamp(rc, occupancy(rc, v2));
-    if (z == 0) y0 = y;
-    trans *= 1.0 - (double)y;
   }
-  const int yrow = ray / P.W, x = ray - yrow * P.W;
-  proj[(size_t)b * HW + (P.H - 1 - yrow) * P.W + x] = (float)(1.0 - trans + (double)rc.em1 * (double)y0);
+  zcol_fwd_epilogue(P, rc, b, ray, live, trans, y0, proj, trans_out, la);
 }
 
 // Generic depth / tap count: same arithmetic, column re-read from global (L1/L2 serve the re-reads).
 __global__ __launch_bounds__(kColThreads) void k_zcol_fwd_dyn(DpcParams P, RayHost rh, const float* __restrict__ Tbuf,
                                                               const float* __restrict__ s, TapsDyn taps,
-                                                              float* __restrict__ smoothed, float* __restrict__ proj) {
+                                                              float* __restrict__ smoothed, float* __restrict__ proj,
+                                                              float* __restrict__ trans_out, LossArgs la) {
   const int HW = P.H * P.W, D = P.D;
   const int b = blockIdx.y, ray = blockIdx.x * kColThreads + threadIdx.x;
-  if (ray >= HW) return;
+  const bool live = ray < HW;
   const RayConst rc = ray_const(rh, s, b);
-  const float* col = Tbuf + (size_t)b * D * HW + ray;
-  float* out = smoothed + (size_t)b * D * HW + ray;
-  const int R = taps.n > 0 ? (taps.n - 1) / 2 : 0;
   double trans = 1.0;
   float y0 = 0.f;
-  for (int z = 0; z < D; ++z) {
-    float v2;
-    if (taps.n == 0) {
-      v2 = col[(size_t)z * HW];
-    } else {
-      v2 = 0.f;
-      for (int k = 0; k < taps.n; ++k) {
-        const int zz = z + k - R;
-        if (zz >= 0 && zz < D) v2 = fmaf(taps.w[k], col[(size_t)zz * HW], v2);
+  if (live) {
+    const float* col = Tbuf + (size_t)b * D * HW + ray;
+    float* out = smoothed + (size_t)b * D * HW + ray;
+    const int R = taps.n > 0 ? (taps.n - 1) / 2 : 0;
+    for (int z = 0; z < D; ++z) {
+      float v2;
+      if (taps.n == 0) {
+        v2 = col[(size_t)z * HW];
+      } else {
+        v2 = 0.f;
+        for (int k = 0; k < taps.n; ++k) {
+          const int zz = z + k - R;
+          if (zz >= 0 && zz < D) v2 = fmaf(taps.w[k], col[(size_t)zz * HW], v2);
+        }
       }
+      out[(size_t)z * HW] = v2;
+      const float y = drc_clamp(rc, occupancy(rc, v2));
+      if (z == 0) y0 = y;
+      trans *= 1.0 - (double)y;
     }
-    out[(size_t)z * HW] = v2;
-    const float y = drc_clamp(rc, occupancy(rc, v2));
-    if (z == 0) y0 = y;
-    trans *= 1.0 - (double)y;
   }
-  const int yrow = ray / P.W, x = ray - yrow * P.W;
-  proj[(size_t)b * HW + (P.H - 1 - yrow) * P.W + x] = (float)(1.0 - trans + (double)rc.em1 * (double)y0);
+  zcol_fwd_epilogue(P, rc, b, ray, live, trans, y0, proj, trans_out, la);
 }
 
 // ------------------------------------------------------------------------------------------------------
 // Backward 1: DRC backward + scale/clamp backward + adjoint D-pass.                grid (ceil(HW/256), B)
 //   Also zeroes the dq/dt/df accumulators that k_gather_hw adds into, and writes this tile's ds partial.
 // ------------------------------------------------------------------------------------------------------
+// Gradient arriving at this ray's silhouette pixel: either read from dproj, or formed from the fused loss.
+__device__ inline bool cloud_loses(const LossArgs& la, int b) {
+  return la.gt != nullptr && la.winner[b / la.K] != b % la.K;
+}
+__device__ inline float ray_grad(const DpcParams& P, const LossArgs& la, const float* __restrict__ dproj,
+                                 const float* __restrict__ proj, int b, int ray) {
+  const int HW = P.H * P.W;
+  const int yrow = ray / P.W, x = ray - yrow * P.W;
+  const int pix = (P.H - 1 - yrow) * P.W + x;
+  if (la.gt == nullptr) return dproj[(size_t)b * HW + pix];
+  const float up = la.dloss ? *la.dloss : 1.0f;
+  return 2.0f * la.inv_S * up * (proj[(size_t)b * HW + pix] - la.gt[(size_t)(b / la.K) * HW + pix]);
+}
+
 __device__ inline void zcol_bwd_epilogue(float ds_acc, float* ds_part, float* dsmall, int b) {
   __shared__ float red[kColThreads / DPC_WAVE];
   const float w = wave_sum(ds_acc);
@@ -644,37 +732,42 @@ __device__ inline void zcol_bwd_epilogue(float ds_acc, float* ds_part, float* ds
 template <int DD, int RB>
 __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_bwd(DpcParams P, RayHost rh, const float* __restrict__ smoothed,
                                                           const float* __restrict__ s,
-                                                          const float* __restrict__ dproj, TapsT<RB> taps_adj,
+                                                          const float* __restrict__ dproj, const float* __restrict__ proj,
+                                                          const float* __restrict__ trans_in, TapsT<RB> taps_adj,
                                                           float* __restrict__ dT, float* __restrict__ ds_part,
-                                                          float* __restrict__ dsmall) {
+                                                          float* __restrict__ dsmall, LossArgs la) {
   const int HW = P.H * P.W;
   const int b = blockIdx.y, ray = blockIdx.x * kColThreads + threadIdx.x;
   float ds_acc = 0.f;
-  if (ray < HW) {
+  if (ray < HW && !cloud_loses(la, b)) {
     const RayConst rc = ray_const(rh, s, b);
     const float* col = smoothed + (size_t)b * DD * HW + ray;
     float c[DD];
 #pragma unroll
     for (int z = 0; z < DD; ++z) c[z] = col[(size_t)z * HW];
-    double trans = 1.0;
+    float Tf;
+    if (trans_in != nullptr) {
+      Tf = trans_in[(size_t)b * HW + ray];  // saved by the forward
+    } else {
+      double trans = 1.0;
 #pragma unroll
-    for (int z = 0; z < DD; ++z) {
-      trans *= 1.0 - (double)drc_clamp(rc, occupancy(rc, c[z]));
-      if ((z & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      for (int z = 0; z < DD; ++z) {
+        trans *= 1.0 - (double)drc_clamp(rc, occupancy(rc, c[z]));
+        if ((z & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+      }
+      Tf = (float)trans;
+      // Opaque to the optimiser: without it the clamped values and lane masks of all DD voxels computed for
+      // the transmittance are kept live for the loop below (CSE), which spills the column to scratch.
+#pragma unroll
+      for (int z = 0; z < DD; ++z) asm volatile("" : "+v"(c[z]));
     }
-    const float Tf = (float)trans;
-    const int yrow = ray / P.W, x = ray - yrow * P.W;
-    const float g = dproj[(size_t)b * HW + (P.H - 1 - yrow) * P.W + x];
-    // Opaque to the optimiser: without it the clamped values and lane masks of all DD voxels computed for
-    // the transmittance are kept live for the loop below (CSE), which spills the column to scratch.
-#pragma unroll
-    for (int z = 0; z < DD; ++z) asm volatile("" : "+v"(c[z]));
+    const float g = ray_grad(P, la, dproj, proj, b, ray);
 #pragma unroll
     for (int z = 0; z < DD; ++z) {
       float term;
       c[z] = drc_voxel_bwd(rc, c[z], g, Tf, z == 0, term);
       ds_acc += term;
-      // keep the unrolled division chains from being interleaved across voxels (it spills the column)
+      // keep the unrolled per-voxel chains from being interleaved across voxels (it spills the column)
       if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
     float* out = dT + (size_t)b * DD * HW + ray;
@@ -695,20 +788,25 @@ __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_bwd(Dp
 
 __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHost rh, const float* __restrict__ smoothed,
                                                               const float* __restrict__ s,
-                                                              const float* __restrict__ dproj, TapsDyn taps_adj,
+                                                              const float* __restrict__ dproj, const float* __restrict__ proj,
+                                                              const float* __restrict__ trans_in, TapsDyn taps_adj,
                                                               float* __restrict__ dT, float* __restrict__ ds_part,
-                                                              float* __restrict__ dsmall) {
+                                                              float* __restrict__ dsmall, LossArgs la) {
   const int HW = P.H * P.W, D = P.D;
   const int b = blockIdx.y, ray = blockIdx.x * kColThreads + threadIdx.x;
   float ds_acc = 0.f;
-  if (ray < HW) {
+  if (ray < HW && !cloud_loses(la, b)) {
     const RayConst rc = ray_const(rh, s, b);
     const float* col = smoothed + (size_t)b * D * HW + ray;
-    double trans = 1.0;
-    for (int z = 0; z < D; ++z) trans *= 1.0 - (double)drc_clamp(rc, occupancy(rc, col[(size_t)z * HW]));
-    const float Tf = (float)trans;
-    const int yrow = ray / P.W, x = ray - yrow * P.W;
-    const float g = dproj[(size_t)b * HW + (P.H - 1 - yrow) * P.W + x];
+    float Tf;
+    if (trans_in != nullptr) {
+      Tf = trans_in[(size_t)b * HW + ray];
+    } else {
+      double trans = 1.0;
+      for (int z = 0; z < D; ++z) trans *= 1.0 - (double)drc_clamp(rc, occupancy(rc, col[(size_t)z * HW]));
+      Tf = (float)trans;
+    }
+    const float g = ray_grad(P, la, dproj, proj, b, ray);
     const int R = taps_adj.n > 0 ? (taps_adj.n - 1) / 2 : 0;
     float* out = dT + (size_t)b * D * HW + ray;
     for (int z = 0; z < D; ++z) {
@@ -745,11 +843,22 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
                                                             const float* __restrict__ dT,
                                                             const uint64_t* __restrict__ mask,
                                                             const float* __restrict__ ds_part, int n_ds_part,
-                                                            float* __restrict__ dpc, float* __restrict__ dsmall) {
+                                                            float* __restrict__ dpc, float* __restrict__ dsmall,
+                                                            LossArgs la) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
   const int D = P.D, H = P.H, W = P.W, N = P.N, HW = H * W;
   const int Zs = GS ? ZS : zs_rt;
   const int b = blockIdx.y, z0 = blockIdx.x * Zs;
+  if (cloud_loses(la, b)) {  // a losing pose candidate: zero gradient, no work (block-uniform)
+    float* dz = dpc + (size_t)b * N * 3;
+    auto zero3 = [&](const PointRec&, int i) { dz[3 * i + 0] = 0.f; dz[3 * i + 1] = 0.f; dz[3 * i + 2] = 0.f; };
+    for_each_record(cells, b, z0, min(z0 + Zs, D), zero3);
+    if (blockIdx.x == 0) {
+      for_each_record(cells, b, D, D + 1, zero3);
+      if (threadIdx.x == 0) dsmall[(size_t)b * DPC_SMALL_COLS + DPC_COL_DS] = 0.f;
+    }
+    return;
+  }
   const int nzp = min(Zs + 1, D - z0);  // planes present (cell layers + halo)
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int wpp = (HW + 63) / 64;
@@ -762,6 +871,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     constexpr int NPL = ZS + 1;
     red = slab + ((Geo::slab_floats(NPL) + 3) / 4) * 4;
     // planes -> LDS (16-byte global loads, 16-byte LDS stores); absent planes and the row pads are zeroed
+    if (!DPC_ABL(11))
     for (int i = tid; i < NPL * GS * (GS / 4); i += Geo::NT) {
       const int x4 = i % (GS / 4), zy = i / (GS / 4);
       f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -784,9 +894,11 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
       }
       __syncthreads();
     } else {
+      if (!DPC_ABL(8))
       hpass_fast<Geo, GS, RB, NPL, true>(slab, taps_adj, [&](int z, int y, int x, f32x2 val) {
         *reinterpret_cast<f32x2*>(slab + Geo::at(z, y, x)) = val;
       });
+      if (!DPC_ABL(9))
       wpass_fast<Geo, GS, RB, NPL, false, 2>(slab, taps_adj, const_cast<uint32_t*>(mask32), nzp);
     }
   } else {
@@ -827,6 +939,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     if constexpr (GS > 0) return slab[BwdGeo<GS, RB>::at(zz, yy, xx)];
     else return slab[(zz * H + yy) * odd_stride(W) + xx];
   };
+  if (!DPC_ABL(10))
   for_each_record(cells, b, z0, min(z0 + Zs, D), [&](const PointRec& rec, int i) {
     const Cell c = cell_from_record(rec);
     float cv[2][2][2];
@@ -993,7 +1106,7 @@ constexpr int kFwdZs64 = DPC_FWD_ZS64;  // planes per forward slab at G = 64 (4 
 // ---- slab kernel dispatch: specialised when H = W in {32, 64, 128} and the padded slab fits, else generic
 template <int GS, int ZS, int RB>
 int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
-                      uint64_t* mask, hipStream_t st) {
+                      uint64_t* mask, float* sse, hipStream_t st) {
   using Geo = FwdGeo<GS, ZS, RB>;
   constexpr size_t lds = std::max((size_t)ZS * GS * GS * sizeof(unsigned long long), Geo::slab_floats(ZS) * sizeof(float));
   static_assert(lds <= kLdsLimit, "forward slab does not fit LDS");
@@ -1001,20 +1114,20 @@ int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const T
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_splat_hw", kern, dim3((p->D + ZS - 1) / ZS, p->B), dim3(Geo::NT), lds, st, *p, cells,
-             make_taps<RB>(kxy, pxy, false), ZS, raw, Tbuf, mask);
+             make_taps<RB>(kxy, pxy, false), ZS, raw, Tbuf, mask, sse);
   return launch_ok();
 }
 
 template <int RB>
 int launch_splat(const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
-                 uint64_t* mask, hipStream_t st) {
+                 uint64_t* mask, float* sse, hipStream_t st) {
   if (p->H == p->W) {
     if constexpr (RB <= 4) {
-      if (p->H == 32) return launch_splat_fast<32, 4, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, st);
-      if (p->H == 128) return launch_splat_fast<128, 1, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, st);
+      if (p->H == 32) return launch_splat_fast<32, 4, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, st);
+      if (p->H == 128) return launch_splat_fast<128, 1, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, st);
     }
     if constexpr (RB <= 10) {
-      if (p->H == 64) return launch_splat_fast<64, kFwdZs64, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, st);
+      if (p->H == 64) return launch_splat_fast<64, kFwdZs64, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, st);
     }
   }
   const int fit = planes_fit(p);
@@ -1025,14 +1138,14 @@ int launch_splat(const DpcParams* p, Cells cells, const float* kxy, const TapPla
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_splat_hw", kern, dim3((p->D + Zs - 1) / Zs, p->B), dim3(slab_threads(p)), lds, st, *p, cells,
-             make_taps<RB>(kxy, pxy, false), Zs, raw, Tbuf, mask);
+             make_taps<RB>(kxy, pxy, false), Zs, raw, Tbuf, mask, sse);
   return launch_ok();
 }
 
 template <int GS, int ZS, int RB>
 int launch_gather_fast(const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
                        const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask,
-                       const float* ds_part, int ntile, float* dpc, float* dsmall, hipStream_t st) {
+                       const float* ds_part, int ntile, float* dpc, float* dsmall, const LossArgs& la, hipStream_t st) {
   using Geo = BwdGeo<GS, RB>;
   constexpr size_t lds = (((Geo::slab_floats(ZS + 1) + 3) / 4) * 4 + kRedFloats) * sizeof(float);
   static_assert(lds <= kLdsLimit, "backward slab does not fit LDS");
@@ -1040,21 +1153,21 @@ int launch_gather_fast(const DpcParams* p, Cells cells, const float* pc, const f
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_gather_hw", kern, dim3((p->D + ZS - 1) / ZS, p->B), dim3(Geo::NT), lds, st, *p, cells, pc, q, t, f,
-             make_taps<RB>(kxy, pxy, true), ZS, dT, mask, ds_part, ntile, dpc, dsmall);
+             make_taps<RB>(kxy, pxy, true), ZS, dT, mask, ds_part, ntile, dpc, dsmall, la);
   return launch_ok();
 }
 
 template <int RB>
 int launch_gather(const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
                   const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part,
-                  int ntile, float* dpc, float* dsmall, hipStream_t st) {
+                  int ntile, float* dpc, float* dsmall, const LossArgs& la, hipStream_t st) {
   if (p->H == p->W) {
     if constexpr (RB <= 4) {
-      if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, st);
-      if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, st);
-      if (p->H == 64) return launch_gather_fast<64, 8, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, st);
+      if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
+      if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
+      if (p->H == 64) return launch_gather_fast<64, 8, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
     } else if constexpr (RB <= 10) {
-      if (p->H == 64) return launch_gather_fast<64, 7, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, st);
+      if (p->H == 64) return launch_gather_fast<64, 7, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
     }
   }
   const int fit = planes_fit(p);
@@ -1065,7 +1178,7 @@ int launch_gather(const DpcParams* p, Cells cells, const float* pc, const float*
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_gather_hw", kern, dim3((p->D + Zs - 1) / Zs, p->B), dim3(slab_threads(p)), lds, st, *p, cells, pc, q, t, f,
-             make_taps<RB>(kxy, pxy, true), Zs, dT, mask, ds_part, ntile, dpc, dsmall);
+             make_taps<RB>(kxy, pxy, true), Zs, dT, mask, ds_part, ntile, dpc, dsmall, la);
   return launch_ok();
 }
 
@@ -1116,12 +1229,17 @@ int dpc_splat_fwd(const DpcParams* p, const void* tr, int tr_is_f64, void* cells
   hipStream_t st = (hipStream_t)stream;
   if ((rc = launch_locate(p, tr_is_f64 ? 2 : 1, tr, nullptr, nullptr, nullptr, nullptr, cells, st)) != DPC_OK) return rc;
   const TapPlan none{0, 0, 0};
-  return launch_splat<0>(p, cells_view(p, cells), nullptr, none, vox, nullptr, nullptr, st);
+  return launch_splat<0>(p, cells_view(p, cells), nullptr, none, vox, nullptr, nullptr, nullptr, st);
 }
 
-int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
-                    const float* s, const float* host_kern_xy, const float* host_kern_z, float* tr_pc, void* cells,
-                    float* raw, float* smoothed, uint64_t* mask, float* proj, void* workspace, void* stream) {
+}  // extern "C"
+
+namespace {
+
+int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, const float* s,
+                     const float* host_kern_xy, const float* host_kern_z, float* tr_pc, void* cells, float* raw,
+                     float* smoothed, uint64_t* mask, float* proj, float* trans, const LossArgs& la, void* workspace,
+                     hipStream_t st) {
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
   if (!q || !smoothed || !mask || !proj || !workspace) return DPC_ERR_NULL;
@@ -1131,11 +1249,10 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
   const TapPlan pxy = plan_taps(host_kern_xy, p->taps_xy), pz = plan_taps(host_kern_z, p->taps_z);
   if (pxy.bucket < 0) return DPC_ERR_TAPS;  // in-LDS passes need a radius bucket; caller composes the stage ops
   float* Tbuf = static_cast<float*>(workspace);
-  hipStream_t st = (hipStream_t)stream;
 
   if ((rc = launch_locate(p, 0, pc, q, t, f, tr_pc, cells, st)) != DPC_OK) return rc;
   const Cells cv = cells_view(p, cells);
-#define LAUNCH_SPLAT(RB) rc = launch_splat<RB>(p, cv, host_kern_xy, pxy, raw, Tbuf, mask, st)
+#define LAUNCH_SPLAT(RB) rc = launch_splat<RB>(p, cv, host_kern_xy, pxy, raw, Tbuf, mask, la.sse, st)
   DPC_FOR_BUCKET(pxy.bucket, LAUNCH_SPLAT)
 #undef LAUNCH_SPLAT
   if (rc != DPC_OK) return rc;
@@ -1146,26 +1263,27 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
 #define LAUNCH_ZFWD(RB)                                                                                          \
   {                                                                                                              \
     const TapsT<RB> tz = make_taps<RB>(host_kern_z, pz, false);                                                  \
-    if (p->D == 32) { DPC_LAUNCH("k_zcol_fwd", (k_zcol_fwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj); done = true; } \
-    else if (p->D == 64) { DPC_LAUNCH("k_zcol_fwd", (k_zcol_fwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj); done = true; } \
-    else if (p->D == 128) { DPC_LAUNCH("k_zcol_fwd", (k_zcol_fwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj); done = true; } \
+    if (p->D == 32) { DPC_LAUNCH("k_zcol_fwd", (k_zcol_fwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj, trans, la); done = true; } \
+    else if (p->D == 64) { DPC_LAUNCH("k_zcol_fwd", (k_zcol_fwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj, trans, la); done = true; } \
+    else if (p->D == 128) { DPC_LAUNCH("k_zcol_fwd", (k_zcol_fwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tz, smoothed, proj, trans, la); done = true; } \
   }
   if (pz.bucket >= 0) { DPC_FOR_BUCKET(pz.bucket, LAUNCH_ZFWD) }
 #undef LAUNCH_ZFWD
   if (!done) {
     DPC_LAUNCH("k_zcol_fwd", k_zcol_fwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s,
-               make_taps_dyn(host_kern_z, p->taps_z, false), smoothed, proj);
+               make_taps_dyn(host_kern_z, p->taps_z, false), smoothed, proj, trans, la);
   }
   return launch_ok();
 }
 
-int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
-                    const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
-                    const float* smoothed, const uint64_t* mask, const float* dproj, float* dpc, float* dsmall,
-                    void* workspace, void* stream) {
+int project_bwd_impl(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, const float* s,
+                     const float* host_kern_xy, const float* host_kern_z, const void* cells, const float* smoothed,
+                     const uint64_t* mask, const float* dproj, const float* proj, const float* trans, const LossArgs& la,
+                     float* dpc, float* dsmall, void* workspace, hipStream_t st) {
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
-  if (!q || !smoothed || !mask || !dproj || !dsmall || !workspace) return DPC_ERR_NULL;
+  if (!q || !smoothed || !mask || !dsmall || !workspace) return DPC_ERR_NULL;
+  if (la.gt == nullptr ? !dproj : (!proj || !la.winner)) return DPC_ERR_NULL;
   if (p->N > 0 && p->B > 0 && (!pc || !cells || !dpc)) return DPC_ERR_NULL;
   if ((p->taps_xy > 0 && !host_kern_xy) || (p->taps_z > 0 && !host_kern_z)) return DPC_ERR_NULL;
   if (p->B == 0) return DPC_OK;
@@ -1174,7 +1292,6 @@ int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const f
   float* dT = static_cast<float*>(workspace);
   const size_t grid_bytes = (((size_t)p->B * p->D * p->H * p->W * sizeof(float) + 255) / 256) * 256;
   float* ds_part = reinterpret_cast<float*>(static_cast<char*>(workspace) + grid_bytes);
-  hipStream_t st = (hipStream_t)stream;
   const int ntile = col_tiles(p);
   dim3 gcol(ntile, p->B);
   const RayHost rh = ray_host(p);
@@ -1183,24 +1300,76 @@ int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const f
 #define LAUNCH_ZBWD(RB)                                                                                           \
   {                                                                                                               \
     const TapsT<RB> tz = make_taps<RB>(host_kern_z, pz, true);                                                    \
-    if (p->D == 32) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, tz, dT, ds_part, dsmall); done = true; } \
-    else if (p->D == 64) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, tz, dT, ds_part, dsmall); done = true; } \
-    else if (p->D == 128) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, tz, dT, ds_part, dsmall); done = true; } \
+    if (p->D == 32) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, proj, trans, tz, dT, ds_part, dsmall, la); done = true; } \
+    else if (p->D == 64) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, proj, trans, tz, dT, ds_part, dsmall, la); done = true; } \
+    else if (p->D == 128) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, proj, trans, tz, dT, ds_part, dsmall, la); done = true; } \
   }
   if (pz.bucket >= 0) { DPC_FOR_BUCKET(pz.bucket, LAUNCH_ZBWD) }
 #undef LAUNCH_ZBWD
   if (!done) {
-    DPC_LAUNCH("k_zcol_bwd", k_zcol_bwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj,
-               make_taps_dyn(host_kern_z, p->taps_z, true), dT, ds_part, dsmall);
+    DPC_LAUNCH("k_zcol_bwd", k_zcol_bwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, proj, trans,
+               make_taps_dyn(host_kern_z, p->taps_z, true), dT, ds_part, dsmall, la);
   }
   if ((rc = launch_ok()) != DPC_OK) return rc;
 
   const Cells cv = cells_view(p, cells);
 #define LAUNCH_GATHER(RB) \
-  rc = launch_gather<RB>(p, cv, pc, q, t, f, host_kern_xy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, st)
+  rc = launch_gather<RB>(p, cv, pc, q, t, f, host_kern_xy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st)
   DPC_FOR_BUCKET(pxy.bucket, LAUNCH_GATHER)
 #undef LAUNCH_GATHER
   return rc;
+}
+
+const LossArgs kNoLoss{nullptr, nullptr, nullptr, nullptr, 1, 1.0f};
+
+}  // namespace
+
+extern "C" {
+
+int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                    const float* s, const float* host_kern_xy, const float* host_kern_z, float* tr_pc, void* cells,
+                    float* raw, float* smoothed, uint64_t* mask, float* proj, float* trans, void* workspace,
+                    void* stream) {
+  return project_fwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, tr_pc, cells, raw, smoothed, mask, proj, trans,
+                          kNoLoss, workspace, (hipStream_t)stream);
+}
+
+int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                    const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
+                    const float* smoothed, const uint64_t* mask, const float* trans, const float* dproj, float* dpc,
+                    float* dsmall, void* workspace, void* stream) {
+  if (!dproj) return DPC_ERR_NULL;
+  return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, smoothed, mask, dproj, nullptr, trans,
+                          kNoLoss, dpc, dsmall, workspace, (hipStream_t)stream);
+}
+
+int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                         const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt,
+                         int num_candidates, float* tr_pc, void* cells, float* smoothed, uint64_t* mask, float* proj,
+                         float* trans, float* sse, float* loss, int32_t* winner, void* workspace, void* stream) {
+  if (!p || !gt || !sse || !loss || !winner) return DPC_ERR_NULL;
+  if (num_candidates < 1 || p->B % num_candidates != 0) return DPC_ERR_SHAPE;
+  const int S = p->B / num_candidates;
+  const LossArgs la{gt, sse, nullptr, nullptr, num_candidates, S > 0 ? 1.0f / (float)S : 0.f};
+  int rc = project_fwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, tr_pc, cells, nullptr, smoothed, mask, proj,
+                            trans, la, workspace, (hipStream_t)stream);
+  if (rc != DPC_OK || p->B == 0) return rc;
+  DPC_LAUNCH("k_loss_finalize", k_loss_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)sse, S,
+             num_candidates, la.inv_S, loss, winner);
+  return launch_ok();
+}
+
+int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                         const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
+                         const float* smoothed, const uint64_t* mask, const float* proj, const float* trans,
+                         const float* gt, int num_candidates, const int32_t* winner, const float* dloss, float* dpc,
+                         float* dsmall, void* workspace, void* stream) {
+  if (!p || !gt || !winner || !proj) return DPC_ERR_NULL;
+  if (num_candidates < 1 || p->B % num_candidates != 0) return DPC_ERR_SHAPE;
+  const int S = p->B / num_candidates;
+  const LossArgs la{gt, nullptr, winner, dloss, num_candidates, S > 0 ? 1.0f / (float)S : 0.f};
+  return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, smoothed, mask, nullptr, proj, trans, la,
+                          dpc, dsmall, workspace, (hipStream_t)stream);
 }
 
 }  // extern "C"

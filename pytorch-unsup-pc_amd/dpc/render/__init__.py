@@ -17,14 +17,14 @@ import numpy as np
 import torch
 
 from . import _native
-from ._ops import Drc, Geometry, ProjectFused, SilhouetteLoss, Smooth, Splat, Transform
+from ._ops import Drc, Geometry, ProjectFused, ProjectLossFused, SilhouetteLoss, Smooth, Splat, Transform
 
 __all__ = [
     "pointcloud_project_fast", "pointcloud_project", "pc_perspective_transform", "pointcloud2voxels3d_fast",
     "smoothen_voxels3d", "smooth_voxels3d", "smoothing_kernel", "gauss_kernel_1d", "separable_kernels",
     "drc_projection", "drc_event_probabilities", "drc_depth_projection", "drc_depth_grid", "pc_point_dropout",
     "quaternion_rotate", "quaternion_multiply", "quaternion_conjugate", "quaternion_normalise",
-    "get_smooth_sigma", "get_dropout_prob", "ProjectionOutputs", "silhouette_loss",
+    "get_smooth_sigma", "get_dropout_prob", "ProjectionOutputs", "silhouette_loss", "pointcloud_project_loss",
 ]
 
 
@@ -295,6 +295,38 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation, 
 
 
 pointcloud_project = pointcloud_project_fast
+
+
+def pointcloud_project_loss(cfg, point_cloud, transform, predicted_translation, all_rgb, kernel=None,
+                            scaling_factor=None, focal_length=None, gt=None, num_candidates=1, smooth=True):
+    """pointcloud_project_fast followed by the model's projection loss, as ONE autograd node.
+
+    What ModelPointCloud does in two steps -- compute_projection (dpc/models/model_pc_to.py:239-282) then
+    add_proj_loss / proj_loss_pose_candidates (:339-385, 410-440) -- with the loss folded into the ray-march
+    kernels: `gt` [S,H,W,1] is the mask already pooled to the silhouette size, `point_cloud` holds
+    S*num_candidates clouds (candidate-minor, like tf_repeat_0).  Returns (loss, outputs, winner): the scalar
+    loss sum_s min_k sum (gt-pred)^2 / S, the usual output dict (`proj` from this pass, the rest lazy), and the
+    winning candidate per sample.  Falls back to pointcloud_project_fast + silhouette_loss when the Gaussian is
+    too long for the fused kernels."""
+    if all_rgb is not None:
+        raise NotImplementedError("all_rgb: the rgb branch of the reference is dead (point_cloud_to.py:64 AttributeError)")
+    if gt is None:
+        raise ValueError("gt (pooled masks [S,H,W,1]) is required")
+    _check_live_branches(cfg)
+    geom = _geometry(cfg, kernel if smooth else None)
+    staged = lambda: _project_staged(cfg, geom, point_cloud, transform, predicted_translation, focal_length,
+                                     scaling_factor, smooth)
+    try:
+        loss, proj, winner = ProjectLossFused.apply(point_cloud, transform, predicted_translation, focal_length,
+                                                    scaling_factor, gt, geom, num_candidates)
+    except _native.DpcError as e:
+        if e.code != _native.DPC_ERR_TAPS:
+            raise
+        out = pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation, None, kernel, scaling_factor,
+                                      focal_length, smooth)
+        loss, winner = silhouette_loss(out["proj"], gt, num_candidates)
+        return loss, out, winner
+    return loss, ProjectionOutputs(proj, staged), winner
 
 
 def pc_point_dropout(points, rgb, keep_prob):

@@ -12,7 +12,7 @@ import torch
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "csrc"))
 LIB_PATH = os.path.join(_CSRC, "libdpc_render.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 DPC_MAX_TAPS = 63
 DPC_SMALL_COLS = 12
 COL_DQ, COL_DS, COL_DT, COL_DF = 0, 4, 5, 8
@@ -22,7 +22,7 @@ DPC_ERR_LDS = -4
 # every symbol include/dpc_render.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = (
     "dpc_abi_version", "dpc_strerror", "dpc_mask_words_per_plane", "dpc_cells_bytes", "dpc_workspace_bytes", "dpc_locate",
-    "dpc_project_fwd", "dpc_project_bwd", "dpc_transform_fwd", "dpc_transform_bwd",
+    "dpc_project_fwd", "dpc_project_bwd", "dpc_project_loss_fwd", "dpc_project_loss_bwd", "dpc_transform_fwd", "dpc_transform_bwd",
     "dpc_splat_fwd", "dpc_splat_bwd", "dpc_smooth", "dpc_drc_fwd", "dpc_drc_bwd",
     "dpc_silhouette_loss", "dpc_profile_enable", "dpc_profile_disable", "dpc_profile_count", "dpc_profile_get",
 )
@@ -64,11 +64,15 @@ def lib():
         L.dpc_cells_bytes.argtypes = [pp]
         L.dpc_workspace_bytes.restype = ctypes.c_size_t
         L.dpc_workspace_bytes.argtypes = [pp]
-        for name, nptr in (("dpc_project_fwd", 15), ("dpc_project_bwd", 15), ("dpc_transform_fwd", 6),
+        for name, nptr in (("dpc_project_fwd", 16), ("dpc_project_bwd", 16), ("dpc_transform_fwd", 6),
                            ("dpc_transform_bwd", 8), ("dpc_drc_fwd", 5), ("dpc_drc_bwd", 6), ("dpc_locate", 7)):
             fn = getattr(L, name)
             fn.restype = ctypes.c_int
             fn.argtypes = [pp] + [vp] * nptr
+        L.dpc_project_loss_fwd.restype = ctypes.c_int
+        L.dpc_project_loss_fwd.argtypes = [pp] + [vp] * 8 + [ctypes.c_int] + [vp] * 11
+        L.dpc_project_loss_bwd.restype = ctypes.c_int
+        L.dpc_project_loss_bwd.argtypes = [pp] + [vp] * 13 + [ctypes.c_int] + [vp] * 6
         L.dpc_splat_fwd.restype = ctypes.c_int
         L.dpc_splat_fwd.argtypes = [pp, vp, ctypes.c_int, vp, vp, vp]
         L.dpc_splat_bwd.restype = ctypes.c_int

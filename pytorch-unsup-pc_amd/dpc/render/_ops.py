@@ -119,18 +119,19 @@ class ProjectFused(torch.autograd.Function):
         mask = torch.empty((B, geom.D, wpp), dtype=torch.int64, device=dev)
         cells = _new_cells(P, dev)
         proj = torch.empty((B, geom.H, geom.W, 1), dtype=torch.float32, device=dev)
+        trans = torch.empty((B, geom.H, geom.W), dtype=torch.float32, device=dev)
         ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
         kxy, kz = geom.kern_ptrs()
         with torch.cuda.device(dev):
             rc = L.dpc_project_fwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
-                                   None, N.ptr(cells), None, N.ptr(smoothed), N.ptr(mask), N.ptr(proj), N.ptr(ws),
-                                   N.stream_ptr(dev))
+                                   None, N.ptr(cells), None, N.ptr(smoothed), N.ptr(mask), N.ptr(proj), N.ptr(trans),
+                                   N.ptr(ws), N.stream_ptr(dev))
         N.check(rc, "dpc_project_fwd")
         ctx.geom = geom
         ctx.inputs = tuple(_meta(x) for x in (pc, q, t, f, s))
         ctx.save_for_backward(pc32, q32, t32 if t32 is not None else pc32.new_empty(0),
                               f32 if f32 is not None else pc32.new_empty(0),
-                              s32 if s32 is not None else pc32.new_empty(0), smoothed, mask, cells)
+                              s32 if s32 is not None else pc32.new_empty(0), smoothed, mask, cells, trans)
         ctx.has = (t is not None, f is not None, s is not None)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(smoothed)
@@ -140,7 +141,7 @@ class ProjectFused(torch.autograd.Function):
     def backward(ctx, dproj, _dsmoothed):
         if dproj is None:
             return None, None, None, None, None, None
-        pc32, q32, t32, f32, s32, smoothed, mask, cells = ctx.saved_tensors
+        pc32, q32, t32, f32, s32, smoothed, mask, cells, trans = ctx.saved_tensors
         has_t, has_f, has_s = ctx.has
         t32 = t32 if has_t else None
         f32 = f32 if has_f else None
@@ -157,14 +158,89 @@ class ProjectFused(torch.autograd.Function):
         kxy, kz = geom.kern_ptrs()
         with torch.cuda.device(dev):
             rc = L.dpc_project_bwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
-                                   N.ptr(cells), N.ptr(smoothed), N.ptr(mask), N.ptr(dproj32), N.ptr(dpc), N.ptr(dsmall),
-                                   N.ptr(ws), N.stream_ptr(dev))
+                                   N.ptr(cells), N.ptr(smoothed), N.ptr(mask), N.ptr(trans), N.ptr(dproj32), N.ptr(dpc),
+                                   N.ptr(dsmall), N.ptr(ws), N.stream_ptr(dev))
         N.check(rc, "dpc_project_bwd")
         pc, q, t, f, s = ctx.inputs
         return (_like_input(dpc, pc), _like_input(dsmall[:, N.COL_DQ:N.COL_DQ + 4], q),
                 _like_input(dsmall[:, N.COL_DT:N.COL_DT + 3], t) if has_t else None,
                 _like_input(dsmall[:, N.COL_DF:N.COL_DF + 1], f) if has_f else None,
                 _like_input(dsmall[:, N.COL_DS:N.COL_DS + 1], s) if has_s else None, None)
+
+
+class ProjectLossFused(torch.autograd.Function):
+    """pointcloud_project_fast + the caller's silhouette loss (add_proj_loss / proj_loss_pose_candidates) in one
+    autograd node: 4 launches forward (locate, splat, ray march + squared error, finalize), 2 backward.  The
+    silhouette gradient is formed on the fly from proj and gt scaled by the incoming dloss (device scalar);
+    losing pose candidates skip their backward.
+
+    forward(pc, q, t, f, s, gt [S,H,W,1], geom, K) -> (loss [], proj [B,H,W,1], winner [S] int32)
+    """
+
+    @staticmethod
+    def forward(ctx, pc, q, t, f, s, gt, geom, num_candidates):
+        dev = N.require_device(pc, q, t, f, s, gt)
+        L = N.lib()
+        pc32, q32, t32, f32, s32, gt32 = _f32(pc), _f32(q), _f32(t), _f32(f), _f32(s), _f32(gt)
+        B, Npts = pc32.shape[0], pc32.shape[1]
+        K = int(num_candidates)
+        if K < 1 or B % K:
+            raise ValueError("%d clouds is not a multiple of %d pose candidates" % (B, K))
+        S = B // K
+        if gt32.shape[0] != S or gt32[0].numel() != geom.H * geom.W:
+            raise ValueError("gt must be [%d,%d,%d,1] (masks pooled to the silhouette size), got %s"
+                             % (S, geom.H, geom.W, tuple(gt32.shape)))
+        P = geom.params(B, Npts)
+        wpp = L.dpc_mask_words_per_plane(ctypes.byref(P))
+        f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        smoothed, proj, trans = f32e(B, geom.D, geom.H, geom.W), f32e(B, geom.H, geom.W, 1), f32e(B, geom.H, geom.W)
+        sse, loss = f32e(B), torch.empty((), dtype=torch.float32, device=dev)
+        mask = torch.empty((B, geom.D, wpp), dtype=torch.int64, device=dev)
+        winner = torch.empty((S,), dtype=torch.int32, device=dev)
+        cells = _new_cells(P, dev)
+        ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
+        kxy, kz = geom.kern_ptrs()
+        with torch.cuda.device(dev):
+            rc = L.dpc_project_loss_fwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
+                                        N.ptr(gt32), K, None, N.ptr(cells), N.ptr(smoothed), N.ptr(mask), N.ptr(proj),
+                                        N.ptr(trans), N.ptr(sse), N.ptr(loss), N.ptr(winner), N.ptr(ws), N.stream_ptr(dev))
+        N.check(rc, "dpc_project_loss_fwd")
+        ctx.geom, ctx.K = geom, K
+        ctx.inputs = tuple(_meta(x) for x in (pc, q, t, f, s))
+        empty = pc32.new_empty(0)
+        ctx.save_for_backward(pc32, q32, t32 if t32 is not None else empty, f32 if f32 is not None else empty,
+                              s32 if s32 is not None else empty, gt32, smoothed, mask, cells, proj, trans, winner)
+        ctx.has = (t is not None, f is not None, s is not None)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(proj, winner)
+        return loss, proj, winner
+
+    @staticmethod
+    def backward(ctx, dloss, _dproj, _dwinner):
+        if dloss is None:
+            return (None,) * 8
+        pc32, q32, t32, f32, s32, gt32, smoothed, mask, cells, proj, trans, winner = ctx.saved_tensors
+        has_t, has_f, has_s = ctx.has
+        t32, f32, s32 = (t32 if has_t else None), (f32 if has_f else None), (s32 if has_s else None)
+        geom, dev, L = ctx.geom, pc32.device, N.lib()
+        B, Npts = pc32.shape[0], pc32.shape[1]
+        P = geom.params(B, Npts)
+        dl = dloss.detach().to(torch.float32).reshape(())
+        dpc = torch.empty_like(pc32)
+        dsmall = torch.empty((B, N.DPC_SMALL_COLS), dtype=torch.float32, device=dev)
+        ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
+        kxy, kz = geom.kern_ptrs()
+        with torch.cuda.device(dev):
+            rc = L.dpc_project_loss_bwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
+                                        N.ptr(cells), N.ptr(smoothed), N.ptr(mask), N.ptr(proj), N.ptr(trans), N.ptr(gt32),
+                                        ctx.K, N.ptr(winner), N.ptr(dl), N.ptr(dpc), N.ptr(dsmall), N.ptr(ws),
+                                        N.stream_ptr(dev))
+        N.check(rc, "dpc_project_loss_bwd")
+        pc, q, t, f, s = ctx.inputs
+        return (_like_input(dpc, pc), _like_input(dsmall[:, N.COL_DQ:N.COL_DQ + 4], q),
+                _like_input(dsmall[:, N.COL_DT:N.COL_DT + 3], t) if has_t else None,
+                _like_input(dsmall[:, N.COL_DF:N.COL_DF + 1], f) if has_f else None,
+                _like_input(dsmall[:, N.COL_DS:N.COL_DS + 1], s) if has_s else None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -3,7 +3,7 @@ ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'pytorch-unsup-pc_amd'))
 import torch
 from dpc.render import _native
-_native.LIB_PATH=os.path.join(ROOT,'scratch','abl','libdpc_render_z%s.so'%sys.argv[1])
+_native.LIB_PATH=os.path.join(ROOT,'scratch','abl','libdpc_render_z4.so')
 import dpc.render as R
 from oracle.dpc_oracle import Cfg, synth_inputs
 B,N,G=32,8000,64
@@ -17,8 +17,10 @@ def step():
     pc.grad=q.grad=s.grad=None
     proj=R.pointcloud_project_fast(cfg,pc,q,None,None,kern,scaling_factor=s)["proj"]
     loss,_=R.silhouette_loss(proj,gt); loss.backward()
-for name,v in [("full",0),("no load",1<<11),("no H",1<<8),("no W",1<<9),("no gather",1<<10),("no H,W",3<<8),("only load",7<<8),("nothing",15<<8)]:
-    L.dpc_debug_set_ablate(v)
-    for _ in range(3): step()
-    prof=_native.profile_kernels(lambda:[step() for _ in range(20)], torch.device('cuda'))
-    print("%-22s"%name, {k:"%.1f"%(1e3*sum(x[5:])/len(x[5:])) for k,x in prof.items() if k in ('k_gather_hw',)})
+VARIANTS=[("full",0),("A:no zero",1),("A:no scatter",16),("A:no W",4),("A:no H",8),("A:nothing but convert",1|16|4|8),
+          ("D:no load",1<<11),("D:no H",1<<8),("D:no W",1<<9),("D:no gather",1<<10),("D:nothing",15<<8)]
+if __name__=="__main__":
+    for name,v in VARIANTS:
+        L.dpc_debug_set_ablate(v)
+        for _ in range(20): step()
+        torch.cuda.synchronize()

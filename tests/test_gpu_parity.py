@@ -394,6 +394,38 @@ def test_silhouette_loss_candidates(R, O, golden):
     close(pred1.grad, 2 * (pred1.detach() - gt) / gt.shape[0], TOL, "K=1 dpred")
 
 
+@pytest.mark.parametrize("K", [1, 4])
+def test_project_loss_fused(R, O, K):
+    """pointcloud_project_loss (loss folded into the ray-march kernels, losing candidates skipped) vs the oracle's
+    projection followed by the reference's min-of-K loss."""
+    S, N, G = 3, 900, 32
+    B = S * K
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    pc, q, s, _, t, _ = O.synth_inputs(B, N, G, 555 + K, with_t=True)
+    gtS = O.synth_inputs(S, 1, G, 77)[3]
+    leaf = lambda x: x.clone().requires_grad_(True)
+    cp, cq, cs, ct = leaf(pc), leaf(q), leaf(s), leaf(t)
+    ref = O.pointcloud_project_fast(cfg, cp, cq, ct, None, O.smoothing_kernel(cfg, 1.2), scaling_factor=cs)
+    rloss, rwin = O.proj_loss_pose_candidates(gtS, ref["proj"], K)
+    (2.5 * rloss).backward()
+    gp, gq, gs, gtt = dev(pc, True), dev(q, True), dev(s, True), dev(t, True)
+    loss, out, win = R.pointcloud_project_loss(cfg, gp, gq, gtt, None, R.smoothing_kernel(cfg, 1.2), scaling_factor=gs,
+                                               gt=dev(gtS), num_candidates=K)
+    (2.5 * loss).backward()
+    assert np.array_equal(win.cpu().numpy(), rwin.numpy())
+    close(loss, rloss, TOL, "fused loss")
+    close(out["proj"], ref["proj"], TOL, "proj")
+    close(gp.grad, cp.grad, TOL, "dpc (fused loss)")
+    close(gq.grad, cq.grad, 3e-5, "dq (fused loss)")
+    close(gs.grad, cs.grad, 3e-5, "ds (fused loss)")
+    close(gtt.grad, ct.grad, 3e-5, "dt (fused loss)")
+    if K > 1:  # losing candidates: exact zeros
+        lose = np.ones(B, bool)
+        lose[np.arange(S) * K + rwin.numpy()] = False
+        assert gp.grad[torch.from_numpy(lose).cuda()].abs().max().item() == 0.0
+        assert gq.grad[torch.from_numpy(lose).cuda()].abs().max().item() == 0.0
+
+
 def test_point_dropout_matches_reference_rng(R):
     pts = torch.arange(2 * 10 * 3, dtype=torch.float32, device="cuda").reshape(2, 10, 3)
     np.random.seed(7)
