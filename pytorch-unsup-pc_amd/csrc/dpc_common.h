@@ -293,10 +293,22 @@ __device__ inline float window_dot(const float (&v)[L + 2 * RB], const TapsT<RB>
 // ------------------------------------------------------------------------------------------------------
 // Reductions
 // ------------------------------------------------------------------------------------------------------
+// Wave-wide sum with DPP-modified VALU adds (no LDS traffic, unlike __shfl_xor = ds_bpermute): butterfly inside
+// quads, rotations inside the 16-lane rows, then row_bcast:15 / row_bcast:31 carry row totals upward; lane 63
+// ends with the total, which v_readlane broadcasts.  gfx9-family DPP controls (row_bcast exists on gfx950).
+template <int CTRL>
+__device__ inline float dpp_move(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
 __device__ inline float wave_sum(float v) {
-#pragma unroll
-  for (int off = DPC_WAVE / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, DPC_WAVE);
-  return v;
+  v += dpp_move<0xb1>(v);   // quad_perm:[1,0,3,2]
+  v += dpp_move<0x4e>(v);   // quad_perm:[2,3,0,1]
+  v += dpp_move<0x124>(v);  // row_ror:4
+  v += dpp_move<0x128>(v);  // row_ror:8   -> every lane holds its row's sum
+  v += dpp_move<0x142>(v);  // row_bcast:15 (lanes without a source add 0)
+  v += dpp_move<0x143>(v);  // row_bcast:31
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // Sum NV per-thread values over the block; result valid in thread 0.  red must hold NV * (blockDim/64) floats.

@@ -15,10 +15,9 @@ pc.requires_grad_(True); q.requires_grad_(True); s.requires_grad_(True)
 L=_native.lib(); L.dpc_debug_set_ablate.argtypes=[ctypes.c_int]
 def step():
     pc.grad=q.grad=s.grad=None
-    proj=R.pointcloud_project_fast(cfg,pc,q,None,None,kern,scaling_factor=s)["proj"]
-    loss,_=R.silhouette_loss(proj,gt); loss.backward()
-VARIANTS=[("full",0),("A:no zero",1),("A:no scatter",16),("A:no W",4),("A:no H",8),("A:nothing but convert",1|16|4|8),
-          ("D:no load",1<<11),("D:no H",1<<8),("D:no W",1<<9),("D:no gather",1<<10),("D:nothing",15<<8)]
+    loss,_,_=R.pointcloud_project_loss(cfg,pc,q,None,None,kern,scaling_factor=s,gt=gt); loss.backward()
+VARIANTS=[("full",0),("D:nothing",15<<8),("D:nothing,ret before camera",(15<<8)|(1<<12)),("D:nothing,ret before blocksum",(15<<8)|(1<<13)),("D:nothing,ret after blocksum",(15<<8)|(1<<14)),
+          ("D:all but epilogue(13)",1<<13),("D:ret before camera",1<<12)]
 if __name__=="__main__":
     for name,v in VARIANTS:
         L.dpc_debug_set_ablate(v)
