@@ -52,6 +52,21 @@ def kernel_bytes_per_cloud(n, g):
     }
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (FETCH_SIZE / WRITE_SIZE collected
+    in separate passes by tools/profile_gpu.sh and corrected with the calibration kernels, as MI355X_MICROARCH.md
+    prescribes); None when no profile of this kernel is on file."""
+    path = os.path.join(ROOT, "profiles", "r01_rocprof_summary.json")
+    try:
+        kernels = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for name, rec in kernels.items():
+        if name.split("<")[0] == kernel and rec.get("hbm_bytes_per_launch"):
+            return rec["hbm_bytes_per_launch"]
+    return None
+
+
 def make_inputs(device, seed):
     from oracle.dpc_oracle import synth_inputs  # input generator only (shared with the tests)
 
@@ -185,7 +200,7 @@ def main():
     if dom is not None:
         ach = B * kb[dom] / (kern_ms[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": 1e3 * kern_ms[dom],
+                    "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(dom), "avg_launch_us": 1e3 * kern_ms[dom],
                     "algorithmic_bytes_per_launch": B * kb[dom]}
     step_ach = (B * a_bytes) / (dev_ms * 1e-3 / args.steps) / 1e9
     out = {

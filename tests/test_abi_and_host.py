@@ -1,0 +1,148 @@
+"""CPU-side checks (no GPU, no compute calls): the C-ABI library loads and exports every symbol that
+include/dpc_render.h declares; host-side logic of the Python mirror (kernels, config validation, lazy outputs,
+sharding helpers) behaves like the reference's."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "dpc_render.h")
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dpc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    from dpc.render import _native
+
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libdpc_render.so does not export %s" % n
+    assert sorted(_native.SYMBOLS) == names, "binding list and header disagree: %s" % (set(_native.SYMBOLS) ^ set(names))
+
+
+def test_abi_version_and_error_strings():
+    from dpc.render import _native
+
+    L = _native.lib()
+    text = open(HEADER).read()
+    assert L.dpc_abi_version() == int(re.search(r"#define DPC_ABI_VERSION (\d+)", text).group(1)) == _native.ABI_VERSION
+    for code in range(0, -7, -1):
+        assert _native.strerror(code) and "unknown" not in _native.strerror(code)
+    assert "unknown" in _native.strerror(-99)
+
+
+def test_size_queries_and_validation_without_gpu():
+    from dpc.render import _native
+
+    L = _native.lib()
+    P = _native.DpcParams(32, 8000, 64, 64, 64, 21, 21, 2.0, 1.875, 1e-5, 10.0)
+    assert L.dpc_mask_words_per_plane(ctypes.byref(P)) == 64
+    assert L.dpc_cells_bytes(ctypes.byref(P)) == 32 * 32 * (256 * 20 + 144)
+    ws = L.dpc_workspace_bytes(ctypes.byref(P))
+    assert ws >= 32 * 64 ** 3 * 4 and ws % 256 == 0
+    bad = _native.DpcParams(1, 10, 2048, 64, 64, 0, 0, 2.0, 1.875, 1e-5, 10.0)  # D beyond the 10-bit cell index
+    assert L.dpc_workspace_bytes(ctypes.byref(bad)) == 0
+    # argument validation happens before any launch: NULL pointers / even tap counts are refused on CPU too
+    assert L.dpc_project_fwd(ctypes.byref(P), *([None] * 16)) == -1
+    even = _native.DpcParams(1, 10, 16, 16, 16, 4, 4, 2.0, 1.875, 1e-5, 10.0)
+    assert L.dpc_transform_fwd(ctypes.byref(even), *([None] * 6)) == -3
+
+
+def test_cpu_tensors_are_refused_loudly():
+    import dpc.render as R
+    from oracle.dpc_oracle import Cfg
+
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        R.pointcloud_project_fast(Cfg(vox_size=16), torch.zeros(1, 4, 3), torch.ones(1, 4), None, None)
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        R.pointcloud2voxels3d_fast(Cfg(vox_size=16), torch.zeros(1, 4, 3), None)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from dpc.render import _native
+
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", "/nonexistent/libdpc_render.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _native.lib()
+
+
+def test_kernels_match_oracle_bitwise():
+    import dpc.render as R
+    from oracle import dpc_oracle as O
+
+    for l, sig in [(11, 1.0), (21, 3.0), (21, 0.64), (10, 1.5)]:
+        assert torch.equal(R.gauss_kernel_1d(l, sig), O.gauss_kernel_1d(l, sig))
+    for cfg in (O.Cfg(vox_size=64, pc_gauss_kernel_size=21), O.Cfg(vox_size=32, vox_size_z=16, pc_gauss_kernel_size=11)):
+        for a, b in zip(R.smoothing_kernel(cfg, 1.5), O.smoothing_kernel(cfg, 1.5)):
+            assert a.shape == b.shape and torch.equal(a, b)
+    with pytest.raises(NotImplementedError, match="pc_separable_gauss_filter"):
+        R.smoothing_kernel(O.Cfg(pc_separable_gauss_filter=False), 1.0)
+
+
+def test_schedules_and_quaternion_helpers():
+    import dpc.render as R
+    from oracle import dpc_oracle as O
+
+    cfg = O.Cfg(pc_relative_sigma=3.0, pc_point_dropout=0.07)
+    for step in (0, 100000, 600000):
+        assert R.get_smooth_sigma(cfg, step) == O.get_smooth_sigma(cfg, step)
+        assert R.get_dropout_prob(cfg, step) == O.get_dropout_prob(cfg, step)
+    g = torch.Generator().manual_seed(3)
+    pc, q = torch.rand(2, 5, 3, generator=g, dtype=torch.float64), torch.randn(2, 4, generator=g, dtype=torch.float64)
+    assert torch.allclose(R.quaternion_rotate(pc, q), O.quaternion_rotate(pc, q), atol=1e-14)
+    assert torch.allclose(R.quaternion_rotate(R.quaternion_rotate(pc, q), q, inverse=True), pc, atol=1e-13)
+
+
+def test_projection_outputs_are_lazy():
+    from dpc.render import ProjectionOutputs
+
+    calls = []
+
+    def build():
+        calls.append(1)
+        return {"voxels": "V", "tr_pc": "T", "drc_probs": "P", "proj_depth": "D", "proj": "ignored"}
+
+    out = ProjectionOutputs("PROJ", build)
+    assert sorted(out.keys()) == sorted(["proj", "voxels", "tr_pc", "voxels_rgb", "proj_rgb", "drc_probs", "proj_depth"])
+    assert out["proj"] == "PROJ" and out["proj_rgb"] is None and not calls
+    assert out["drc_probs"] == "P" and out["voxels"] == "V" and len(calls) == 1
+
+
+def test_dead_branches_named_before_any_launch():
+    import dpc.render as R
+    from oracle.dpc_oracle import Cfg
+
+    z = torch.zeros(1, 4, 3)
+    for kw, key in ((dict(pose_quaternion=False), "pose_quaternion"), (dict(ptn_max_projection=True), "ptn_max_projection"),
+                    (dict(drc_tf_cumulative=False), "drc_tf_cumulative")):
+        with pytest.raises(NotImplementedError, match=key):
+            R.pointcloud_project_fast(Cfg(**kw), z, torch.ones(1, 4), None, None)
+    with pytest.raises(NotImplementedError, match="all_rgb"):
+        R.pointcloud_project_fast(Cfg(), z, torch.ones(1, 4), None, z)
+
+
+def test_util_shims_expose_reference_names():
+    import util.drc
+    import util.gauss_kernel
+    import util.point_cloud_to as P
+    import util.quaternion
+
+    for name in ("pc_point_dropout", "pointcloud_project_fast", "pointcloud2voxels3d_fast", "smoothen_voxels3d",
+                 "pc_perspective_transform"):
+        assert callable(getattr(P, name))
+    for name in ("drc_projection", "drc_event_probabilities", "drc_depth_projection", "drc_depth_grid"):
+        assert callable(getattr(util.drc, name))
+    assert callable(util.gauss_kernel.smoothing_kernel) and callable(util.quaternion.quaternion_rotate)
+    np.testing.assert_allclose(util.drc.drc_depth_grid(__import__("oracle.dpc_oracle", fromlist=["Cfg"]).Cfg(), 4).numpy(),
+                               [1.5, 1.75, 2.0, 2.25, 10.0])

@@ -1,0 +1,79 @@
+"""world_size-2 gloo test (CPU) of the N>1 path: sample sharding that keeps pose candidates together, the
+global loss, and the bucketed gradient all-reduce a data-parallel trainer runs above the renderer.  The renderer
+stand-in on CPU is the oracle (test infrastructure); on GPUs each rank calls dpc.render on its own shard."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import dpc_oracle as O
+
+S, K, N, G = 5, 2, 120, 16  # 5 samples (uneven over 2 ranks), 2 pose candidates each
+
+
+def _problem():
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=5)
+    pc, q, s, _, _, _ = O.synth_inputs(S * K, N, G, 31)
+    gt = O.synth_inputs(S, 1, G, 32)[3]
+    torch.manual_seed(5)
+    net = torch.nn.Linear(4, 4, dtype=torch.float64)  # stands for the shared pose net above the renderer
+    return cfg, pc, q, s, gt, net
+
+
+def _local_loss(cfg, pc, q, s, gt, net, lo, hi):
+    """loss of samples [lo, hi): q goes through the shared net, then projection + min-of-K loss."""
+    c0, c1 = lo * K, hi * K
+    qq = net(q[c0:c1].double())
+    out = O.pointcloud_project_fast(cfg, pc[c0:c1], qq, None, None, O.smoothing_kernel(cfg, 0.8), scaling_factor=s[c0:c1])
+    loss, win = O.proj_loss_pose_candidates(gt[lo:hi], out["proj"], K)
+    return loss, win
+
+
+def _worker(rank, world, port, ret):
+    from dpc.render.parallel import BucketedGradAllReduce, global_mean_loss, shard_clouds, shard_samples
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg, pc, q, s, gt, net = _problem()
+        lo, hi = shard_samples(S, rank, world)
+        assert shard_clouds(S, K, rank, world) == (lo * K, hi * K)
+        loss, win = _local_loss(cfg, pc, q, s, gt, net, lo, hi)
+        loss.backward()
+        BucketedGradAllReduce(net.parameters(), bucket_mb=1e-5)(hi - lo, S)  # tiny buckets: several collectives
+        gl = global_mean_loss(loss, hi - lo)
+        ret[rank] = dict(loss=gl.item(), win=win.tolist(), range=(lo, hi),
+                         grads=[p.grad.clone() for p in net.parameters()])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_sharding_matches_single_process():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mgr = mp.get_context("spawn").Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    cfg, pc, q, s, gt, net = _problem()
+    loss, win = _local_loss(cfg, pc, q, s, gt, net, 0, S)
+    loss.backward()
+    assert ret[0]["range"] == (0, 3) and ret[1]["range"] == (3, 5)
+    assert ret[0]["win"] + ret[1]["win"] == win.tolist()
+    for r in (0, 1):
+        assert abs(ret[r]["loss"] - loss.item()) < 1e-12 * max(1.0, abs(loss.item()))
+        for g, p in zip(ret[r]["grads"], net.parameters()):
+            assert torch.allclose(g, p.grad, rtol=1e-10, atol=1e-12)
+
+
+def test_shard_ranges_cover_everything():
+    from dpc.render.parallel import shard_samples
+
+    for n in (0, 1, 7, 32, 33):
+        for w in (1, 2, 3, 8):
+            r = [shard_samples(n, k, w) for k in range(w)]
+            assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            assert max(e - b for b, e in r) - min(e - b for b, e in r) <= 1
