@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DPC_ABI_VERSION 4
+#define DPC_ABI_VERSION 5
 #define DPC_MAX_TAPS 63 /* longest 1-D smoothing kernel accepted (pc_gauss_kernel_size) */
 
 enum {
@@ -58,7 +58,9 @@ typedef struct DpcParams {
   float max_depth;         /* cfg.max_depth                                                              */
 } DpcParams;
 
-/* Columns of the per-cloud small-gradient rows written by the backward entry points ([B, DPC_SMALL_COLS]). */
+/* Small per-cloud gradients written by the backward entry points: one buffer of DPC_SMALL_COLS * B floats made of
+ * contiguous blocks, so each gradient is a dense tensor of its own: dq [B,4] at float offset DPC_COL_DQ*B,
+ * ds [B,1] at DPC_COL_DS*B, dt [B,3] at DPC_COL_DT*B, df [B,1] at DPC_COL_DF*B. */
 enum { DPC_COL_DQ = 0, DPC_COL_DS = 4, DPC_COL_DT = 5, DPC_COL_DF = 8, DPC_SMALL_COLS = 12 };
 
 int dpc_abi_version(void);
@@ -108,8 +110,8 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
  *   dproj [B,H,W] gradient w.r.t. the (flipped) silhouette
  * outputs
  *   dpc    [B,N,3]
- *   dsmall [B,DPC_SMALL_COLS]: dq at cols 0-3, ds at 4, dt at 5-7, df at 8 (ds/dt/df only meaningful when
- *          the matching input was given); fully overwritten, needs no zeroing by the caller. */
+ *   dsmall DPC_SMALL_COLS*B floats in the block layout above (ds/dt/df only meaningful when the matching input
+ *          was given); fully overwritten, needs no zeroing by the caller. */
 int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                     const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
                     const float* smoothed, const uint64_t* mask, const float* trans /* from fwd, or NULL */,
@@ -142,7 +144,7 @@ int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, co
  * dpc/util/quaternion.py:110-132).  out [B,N,3] in (z,y,x) order. */
 int dpc_transform_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                       float* out, void* stream);
-/* dout [B,N,3] -> dpc [B,N,3], dsmall [B,DPC_SMALL_COLS] (dq, dt, df columns; overwritten). */
+/* dout [B,N,3] -> dpc [B,N,3], dsmall (DPC_SMALL_COLS*B floats, block layout above: dq, dt, df; overwritten). */
 int dpc_transform_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                       const float* dout, float* dpc, float* dsmall, void* stream);
 

@@ -726,7 +726,7 @@ __device__ inline void zcol_bwd_epilogue(float ds_acc, float* ds_part, float* ds
     for (int i = 0; i < kColThreads / DPC_WAVE; ++i) tot += red[i];
     ds_part[(size_t)b * gridDim.x + blockIdx.x] = tot;
   }
-  if (blockIdx.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)b * DPC_SMALL_COLS + threadIdx.x] = 0.f;
+  if (blockIdx.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)threadIdx.x * gridDim.y + b] = 0.f;  // [col][B]
 }
 
 template <int DD, int RB>
@@ -855,7 +855,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     for_each_record(cells, b, z0, min(z0 + Zs, D), zero3);
     if (blockIdx.x == 0) {
       for_each_record(cells, b, D, D + 1, zero3);
-      if (threadIdx.x == 0) dsmall[(size_t)b * DPC_SMALL_COLS + DPC_COL_DS] = 0.f;
+      if (threadIdx.x == 0) dsmall[(size_t)DPC_COL_DS * P.B + b] = 0.f;
     }
     return;
   }
@@ -983,16 +983,18 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   if (tid == 0) {
     float dq[4];
     quaternion_grad(cam, vals, dq);
-    float* row = dsmall + (size_t)b * DPC_SMALL_COLS;
+    // dsmall is [DPC_SMALL_COLS][B] with dq stored as a [B,4] block, dt as a [B,3] block (see dpc_render.h)
+    float* dqb = dsmall + (size_t)DPC_COL_DQ * P.B + (size_t)b * 4;
+    float* dtb = dsmall + (size_t)DPC_COL_DT * P.B + (size_t)b * 3;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) atomicAdd(row + DPC_COL_DQ + i, dq[i]);
+    for (int i = 0; i < 4; ++i) atomicAdd(dqb + i, dq[i]);
     if (t != nullptr)
-      for (int i = 0; i < 3; ++i) atomicAdd(row + DPC_COL_DT + i, vals[9 + i]);
-    if (f != nullptr) atomicAdd(row + DPC_COL_DF, vals[12]);
+      for (int i = 0; i < 3; ++i) atomicAdd(dtb + i, vals[9 + i]);
+    if (f != nullptr) atomicAdd(dsmall + (size_t)DPC_COL_DF * P.B + b, vals[12]);
     if (blockIdx.x == 0) {
       float ds = 0.f;
       for (int i = 0; i < n_ds_part; ++i) ds += ds_part[(size_t)b * n_ds_part + i];
-      row[DPC_COL_DS] = ds;
+      dsmall[(size_t)DPC_COL_DS * P.B + b] = ds;
     }
   }
 }

@@ -66,10 +66,11 @@ __global__ __launch_bounds__(kThreads) void k_transform_bwd(DpcParams P, const f
   if (threadIdx.x == 0) {
     float dq[4];
     quaternion_grad(cam, vals, dq);
-    float* row = dsmall + (size_t)b * DPC_SMALL_COLS;
-    for (int i = 0; i < 4; ++i) atomicAdd(row + DPC_COL_DQ + i, dq[i]);
-    for (int i = 0; i < 3; ++i) atomicAdd(row + DPC_COL_DT + i, vals[9 + i]);
-    atomicAdd(row + DPC_COL_DF, vals[12]);
+    float* dqb = dsmall + (size_t)DPC_COL_DQ * P.B + (size_t)b * 4;
+    float* dtb = dsmall + (size_t)DPC_COL_DT * P.B + (size_t)b * 3;
+    for (int i = 0; i < 4; ++i) atomicAdd(dqb + i, dq[i]);
+    for (int i = 0; i < 3; ++i) atomicAdd(dtb + i, vals[9 + i]);
+    atomicAdd(dsmall + (size_t)DPC_COL_DF * P.B + b, vals[12]);
   }
 }
 

@@ -12,7 +12,7 @@ import torch
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "csrc"))
 LIB_PATH = os.path.join(_CSRC, "libdpc_render.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 DPC_MAX_TAPS = 63
 DPC_SMALL_COLS = 12
 COL_DQ, COL_DS, COL_DT, COL_DF = 0, 4, 5, 8

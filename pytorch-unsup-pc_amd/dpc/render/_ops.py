@@ -50,6 +50,12 @@ def _meta(t):
     return None if t is None else (t.dtype, tuple(t.shape))
 
 
+def _small(dsmall, col, width, B):
+    """Dense [B,width] view of one gradient block of the small-gradient buffer (contiguous: autograd takes it
+    without cloning)."""
+    return dsmall[col * B:(col + width) * B].view(B, width)
+
+
 def _like_input(grad, meta):
     """Gradients arrive in the input's dtype and shape, like autograd's would."""
     return None if grad is None or meta is None else grad.to(meta[0]).reshape(meta[1])
@@ -153,7 +159,7 @@ class ProjectFused(torch.autograd.Function):
         P = geom.params(B, Npts)
         dproj32 = dproj.detach().to(torch.float32).contiguous()
         dpc = torch.empty_like(pc32)
-        dsmall = torch.empty((B, N.DPC_SMALL_COLS), dtype=torch.float32, device=dev)
+        dsmall = torch.empty((N.DPC_SMALL_COLS * B,), dtype=torch.float32, device=dev)
         ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
         kxy, kz = geom.kern_ptrs()
         with torch.cuda.device(dev):
@@ -162,10 +168,10 @@ class ProjectFused(torch.autograd.Function):
                                    N.ptr(dsmall), N.ptr(ws), N.stream_ptr(dev))
         N.check(rc, "dpc_project_bwd")
         pc, q, t, f, s = ctx.inputs
-        return (_like_input(dpc, pc), _like_input(dsmall[:, N.COL_DQ:N.COL_DQ + 4], q),
-                _like_input(dsmall[:, N.COL_DT:N.COL_DT + 3], t) if has_t else None,
-                _like_input(dsmall[:, N.COL_DF:N.COL_DF + 1], f) if has_f else None,
-                _like_input(dsmall[:, N.COL_DS:N.COL_DS + 1], s) if has_s else None, None)
+        return (_like_input(dpc, pc), _like_input(_small(dsmall, N.COL_DQ, 4, B), q),
+                _like_input(_small(dsmall, N.COL_DT, 3, B), t) if has_t else None,
+                _like_input(_small(dsmall, N.COL_DF, 1, B), f) if has_f else None,
+                _like_input(_small(dsmall, N.COL_DS, 1, B), s) if has_s else None, None)
 
 
 class ProjectLossFused(torch.autograd.Function):
@@ -227,7 +233,7 @@ class ProjectLossFused(torch.autograd.Function):
         P = geom.params(B, Npts)
         dl = dloss.detach().to(torch.float32).reshape(())
         dpc = torch.empty_like(pc32)
-        dsmall = torch.empty((B, N.DPC_SMALL_COLS), dtype=torch.float32, device=dev)
+        dsmall = torch.empty((N.DPC_SMALL_COLS * B,), dtype=torch.float32, device=dev)
         ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
         kxy, kz = geom.kern_ptrs()
         with torch.cuda.device(dev):
@@ -237,10 +243,10 @@ class ProjectLossFused(torch.autograd.Function):
                                         N.stream_ptr(dev))
         N.check(rc, "dpc_project_loss_bwd")
         pc, q, t, f, s = ctx.inputs
-        return (_like_input(dpc, pc), _like_input(dsmall[:, N.COL_DQ:N.COL_DQ + 4], q),
-                _like_input(dsmall[:, N.COL_DT:N.COL_DT + 3], t) if has_t else None,
-                _like_input(dsmall[:, N.COL_DF:N.COL_DF + 1], f) if has_f else None,
-                _like_input(dsmall[:, N.COL_DS:N.COL_DS + 1], s) if has_s else None, None, None, None)
+        return (_like_input(dpc, pc), _like_input(_small(dsmall, N.COL_DQ, 4, B), q),
+                _like_input(_small(dsmall, N.COL_DT, 3, B), t) if has_t else None,
+                _like_input(_small(dsmall, N.COL_DF, 1, B), f) if has_f else None,
+                _like_input(_small(dsmall, N.COL_DS, 1, B), s) if has_s else None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -269,14 +275,15 @@ class Transform(torch.autograd.Function):
         P = ctx.geom.params(pc32.shape[0], pc32.shape[1])
         dout32 = dout.detach().to(torch.float32).contiguous()
         dpc = torch.empty_like(pc32)
-        dsmall = torch.empty((pc32.shape[0], N.DPC_SMALL_COLS), dtype=torch.float32, device=dev)
+        dsmall = torch.empty((N.DPC_SMALL_COLS * pc32.shape[0],), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             rc = N.lib().dpc_transform_bwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32),
                                            N.ptr(dout32), N.ptr(dpc), N.ptr(dsmall), N.stream_ptr(dev))
         N.check(rc, "dpc_transform_bwd")
+        B = pc32.shape[0]
         pc, q, t, f = ctx.inputs
-        return (_like_input(dpc, pc), _like_input(dsmall[:, N.COL_DQ:N.COL_DQ + 4], q),
-                _like_input(dsmall[:, N.COL_DT:N.COL_DT + 3], t), _like_input(dsmall[:, N.COL_DF:N.COL_DF + 1], f), None)
+        return (_like_input(dpc, pc), _like_input(_small(dsmall, N.COL_DQ, 4, B), q),
+                _like_input(_small(dsmall, N.COL_DT, 3, B), t), _like_input(_small(dsmall, N.COL_DF, 1, B), f), None)
 
 
 class Splat(torch.autograd.Function):
