@@ -369,9 +369,14 @@ __device__ inline void hpass_fast(const float* slab, const TapsT<RB>& taps, Stor
 template <int GS, int ZS, int RB>
 __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells cells, TapsT<RB> taps, int zs_rt,
                                                            float* __restrict__ raw, float* __restrict__ Tbuf,
-                                                           uint64_t* __restrict__ mask, float* __restrict__ sse) {
+                                                           uint64_t* __restrict__ mask, float* __restrict__ sse,
+                                                           float* __restrict__ loss_zero, int* __restrict__ winner_zero) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
-  if (sse != nullptr && blockIdx.x == 0 && threadIdx.x == 0) sse[blockIdx.y] = 0.f;  // k_zcol_fwd accumulates into it
+  if (sse != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {  // k_zcol_fwd accumulates into these
+    sse[blockIdx.y] = 0.f;
+    if (winner_zero != nullptr) winner_zero[blockIdx.y] = 0;   // K == 1: sample == cloud, candidate 0 wins
+    if (loss_zero != nullptr && blockIdx.y == 0) *loss_zero = 0.f;
+  }
   const int D = P.D, H = P.H, W = P.W;
   const int Zs = GS ? ZS : zs_rt;
   const int b = blockIdx.y, z0 = blockIdx.x * Zs;
@@ -541,21 +546,21 @@ __device__ inline float occupancy(const RayConst& r, float v2) {  // scale + cla
 __device__ inline float drc_clamp(const RayConst& r, float v3) { return fminf(fmaxf(v3, r.eps), r.hi); }
 
 // d proj / d v2 for one voxel given the ray's total transmittance; also returns v2 * dL/dv3 * mask for ds.
-// Branch-free: 1/(1-y) via v_rcp_f32 (1 ulp; 1-y >= eps), masks applied with selects.
+// Branch-free and short (this loop is not hidden behind memory): 1/(1-y) via v_rcp_f32 (1 ulp; 1-y >= eps);
+//   inside = (eps <= v3 <= 1-eps)  <=>  the DRC clamp left v3 unchanged  <=>  y == v3;
+//   the scale clamp's pass-through set (0 <= s v2 <= 1) is implied by `inside` (v3 in [eps,1-eps] means the first
+//   clamp did not act either), so one select serves both masks.
 __device__ inline float drc_voxel_bwd(const RayConst& r, float v2, float g, float Tf, bool first, float& ds_term) {
   const float v3 = occupancy(r, v2);
   const float y = drc_clamp(r, v3);
-  const bool inside = (v3 >= r.eps) & (v3 <= r.hi);
   float dv3 = g * fmaf(Tf, __builtin_amdgcn_rcpf(1.0f - y), first ? r.em1 : 0.f);
-  dv3 = inside ? dv3 : 0.f;
+  dv3 = (y == v3) ? dv3 : 0.f;
   if (!r.has_s) {
     ds_term = 0.f;
     return dv3;
   }
-  const float u = r.s * v2;
-  const bool m = (u >= 0.f) & (u <= 1.f);
-  ds_term = m ? v2 * dv3 : 0.f;
-  return m ? r.s * dv3 : 0.f;
+  ds_term = v2 * dv3;
+  return r.s * dv3;
 }
 
 // Fused silhouette loss (dpc/models/model_pc_to.py:339-385, 410-440): cloud b is candidate b % K of sample b / K.
@@ -569,6 +574,8 @@ struct LossArgs {
   const float* dloss;   // device scalar, gradient arriving at the loss (backward); nullptr = 1
   int K;
   float inv_S;
+  float* loss_direct;   // forward, K == 1 only: the scalar loss, accumulated by the ray-march blocks (no finalize launch)
+  int* winner_out;      // forward, K == 1 only: zero-filled by k_splat_hw
 };
 
 __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ sse, int S, int K, float inv_S,
@@ -625,6 +632,7 @@ __device__ inline void zcol_fwd_epilogue(const DpcParams& P, const RayConst& rc,
       float tot = 0.f;
       for (int i = 0; i < kColThreads / DPC_WAVE; ++i) tot += red[i];
       atomicAdd(la.sse + b, tot);
+      if (la.loss_direct != nullptr) atomicAdd(la.loss_direct, tot * la.inv_S);  // K == 1: every cloud wins
     }
   }
 }
@@ -1111,7 +1119,7 @@ constexpr int kFwdZs64 = DPC_FWD_ZS64;  // planes per forward slab at G = 64 (4 
 // ---- slab kernel dispatch: specialised when H = W in {32, 64, 128} and the padded slab fits, else generic
 template <int GS, int ZS, int RB>
 int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
-                      uint64_t* mask, float* sse, hipStream_t st) {
+                      uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, hipStream_t st) {
   using Geo = FwdGeo<GS, ZS, RB>;
   constexpr size_t lds = std::max((size_t)ZS * GS * GS * sizeof(unsigned long long), Geo::slab_floats(ZS) * sizeof(float));
   static_assert(lds <= kLdsLimit, "forward slab does not fit LDS");
@@ -1119,20 +1127,20 @@ int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const T
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_splat_hw", kern, dim3((p->D + ZS - 1) / ZS, p->B), dim3(Geo::NT), lds, st, *p, cells,
-             make_taps<RB>(kxy, pxy, false), ZS, raw, Tbuf, mask, sse);
+             make_taps<RB>(kxy, pxy, false), ZS, raw, Tbuf, mask, sse, loss_zero, winner_zero);
   return launch_ok();
 }
 
 template <int RB>
 int launch_splat(const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
-                 uint64_t* mask, float* sse, hipStream_t st) {
+                 uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, hipStream_t st) {
   if (p->H == p->W) {
     if constexpr (RB <= 4) {
-      if (p->H == 32) return launch_splat_fast<32, 4, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, st);
-      if (p->H == 128) return launch_splat_fast<128, 1, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, st);
+      if (p->H == 32) return launch_splat_fast<32, 4, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, st);
+      if (p->H == 128) return launch_splat_fast<128, 1, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, st);
     }
     if constexpr (RB <= 10) {
-      if (p->H == 64) return launch_splat_fast<64, kFwdZs64, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, st);
+      if (p->H == 64) return launch_splat_fast<64, kFwdZs64, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, st);
     }
   }
   const int fit = planes_fit(p);
@@ -1143,7 +1151,7 @@ int launch_splat(const DpcParams* p, Cells cells, const float* kxy, const TapPla
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_splat_hw", kern, dim3((p->D + Zs - 1) / Zs, p->B), dim3(slab_threads(p)), lds, st, *p, cells,
-             make_taps<RB>(kxy, pxy, false), Zs, raw, Tbuf, mask, sse);
+             make_taps<RB>(kxy, pxy, false), Zs, raw, Tbuf, mask, sse, loss_zero, winner_zero);
   return launch_ok();
 }
 
@@ -1234,7 +1242,7 @@ int dpc_splat_fwd(const DpcParams* p, const void* tr, int tr_is_f64, void* cells
   hipStream_t st = (hipStream_t)stream;
   if ((rc = launch_locate(p, tr_is_f64 ? 2 : 1, tr, nullptr, nullptr, nullptr, nullptr, cells, st)) != DPC_OK) return rc;
   const TapPlan none{0, 0, 0};
-  return launch_splat<0>(p, cells_view(p, cells), nullptr, none, vox, nullptr, nullptr, nullptr, st);
+  return launch_splat<0>(p, cells_view(p, cells), nullptr, none, vox, nullptr, nullptr, nullptr, nullptr, nullptr, st);
 }
 
 }  // extern "C"
@@ -1257,7 +1265,7 @@ int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const 
 
   if ((rc = launch_locate(p, 0, pc, q, t, f, tr_pc, cells, st)) != DPC_OK) return rc;
   const Cells cv = cells_view(p, cells);
-#define LAUNCH_SPLAT(RB) rc = launch_splat<RB>(p, cv, host_kern_xy, pxy, raw, Tbuf, mask, la.sse, st)
+#define LAUNCH_SPLAT(RB) rc = launch_splat<RB>(p, cv, host_kern_xy, pxy, raw, Tbuf, mask, la.sse, la.loss_direct, la.winner_out, st)
   DPC_FOR_BUCKET(pxy.bucket, LAUNCH_SPLAT)
 #undef LAUNCH_SPLAT
   if (rc != DPC_OK) return rc;
@@ -1325,7 +1333,7 @@ int project_bwd_impl(const DpcParams* p, const float* pc, const float* q, const 
   return rc;
 }
 
-const LossArgs kNoLoss{nullptr, nullptr, nullptr, nullptr, 1, 1.0f};
+const LossArgs kNoLoss{nullptr, nullptr, nullptr, nullptr, 1, 1.0f, nullptr, nullptr};
 
 }  // namespace
 
@@ -1355,10 +1363,12 @@ int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, co
   if (!p || !gt || !sse || !loss || !winner) return DPC_ERR_NULL;
   if (num_candidates < 1 || p->B % num_candidates != 0) return DPC_ERR_SHAPE;
   const int S = p->B / num_candidates;
-  const LossArgs la{gt, sse, nullptr, nullptr, num_candidates, S > 0 ? 1.0f / (float)S : 0.f};
+  const bool direct = num_candidates == 1;  // every cloud is its sample's winner: blocks add straight into the loss
+  const LossArgs la{gt, sse, nullptr, nullptr, num_candidates, S > 0 ? 1.0f / (float)S : 0.f,
+                    direct ? loss : nullptr, direct ? winner : nullptr};
   int rc = project_fwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, tr_pc, cells, nullptr, smoothed, mask, proj,
                             trans, la, workspace, (hipStream_t)stream);
-  if (rc != DPC_OK || p->B == 0) return rc;
+  if (rc != DPC_OK || p->B == 0 || direct) return rc;
   DPC_LAUNCH("k_loss_finalize", k_loss_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)sse, S,
              num_candidates, la.inv_S, loss, winner);
   return launch_ok();
@@ -1372,7 +1382,7 @@ int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, co
   if (!p || !gt || !winner || !proj) return DPC_ERR_NULL;
   if (num_candidates < 1 || p->B % num_candidates != 0) return DPC_ERR_SHAPE;
   const int S = p->B / num_candidates;
-  const LossArgs la{gt, nullptr, winner, dloss, num_candidates, S > 0 ? 1.0f / (float)S : 0.f};
+  const LossArgs la{gt, nullptr, winner, dloss, num_candidates, S > 0 ? 1.0f / (float)S : 0.f, nullptr, nullptr};
   return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, smoothed, mask, nullptr, proj, trans, la,
                           dpc, dsmall, workspace, (hipStream_t)stream);
 }
