@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP graph replay")
+    ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -128,13 +129,35 @@ def main():
     pc.requires_grad_(True), q.requires_grad_(True), s.requires_grad_(True)
 
     one = torch.ones((), device=device)
+    ns = max(1, args.streams)
+    if B % ns:
+        raise SystemExit("--streams must divide %d" % B)
+    # per-stream shards (leaves of their own, so each shard's backward accumulates into its own .grad)
+    shards = [[x[i * (B // ns):(i + 1) * (B // ns)].detach().clone().requires_grad_(x.requires_grad) for x in (pc, q, s, gt)]
+              for i in range(ns)]
+    extra = [torch.cuda.Stream(device) for _ in range(ns - 1)]
+    share = torch.full((), 1.0 / ns, device=device)
 
     def step():
-        pc.grad = q.grad = s.grad = None
         # projection + sum((proj-gt)^2)/B in one autograd node (loss folded into the ray-march kernels)
-        loss, _, _ = R.pointcloud_project_loss(cfg, pc, q, None, None, kern, scaling_factor=s, gt=gt)
-        loss.backward(gradient=one)  # preallocated d(loss)=1: no ones-fill launch per step
-        return loss
+        if ns == 1:
+            pc.grad = q.grad = s.grad = None
+            loss, _, _ = R.pointcloud_project_loss(cfg, pc, q, None, None, kern, scaling_factor=s, gt=gt)
+            loss.backward(gradient=one)  # preallocated d(loss)=1: no ones-fill launch per step
+            return loss
+        main = torch.cuda.current_stream(device)
+        losses = []
+        for i, (spc, sq, ss, sgt) in enumerate(shards):
+            st = main if i == 0 else extra[i - 1]
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                spc.grad = sq.grad = ss.grad = None
+                l, _, _ = R.pointcloud_project_loss(cfg, spc, sq, None, None, kern, scaling_factor=ss, gt=sgt)
+                l.backward(gradient=share)  # each shard's loss is a mean over B/ns clouds
+                losses.append(l)
+        for st in extra:
+            main.wait_stream(st)
+        return losses[0]
 
     side = torch.cuda.Stream(device)
     graph = None
@@ -214,7 +237,8 @@ def main():
                                "sigma_rel=0.64 (sigma=0.01), DRC silhouette 64x64 vs mean-pooled 128x128 mask, "
                                "loss sum((proj-gt)^2)/B, backward to pc, q, s",
                    "clouds_per_gpu": B, "points": N_PTS, "grid": G, "taps": KSIZE, "sigma_rel": SIGMA_REL,
-                   "launch": "eager" if graph is None else "hip-graph replay", "sharding": "clouds, no collective"},
+                   "launch": "eager" if graph is None else "hip-graph replay", "streams": ns,
+                   "sharding": "clouds, no collective"},
         "roofline": roofline,
         "roofline_step": {"bound": "hbm", "achieved": step_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": step_ach / HBM_PEAK_GBS, "algorithmic_bytes_per_cloud": a_bytes,

@@ -46,7 +46,7 @@ constexpr int kColThreads = 256;
 constexpr int kLocThreads = 256;                     // points per locate block == points per sorted chunk
 constexpr int kL = 16;                               // outputs per thread in the generic in-LDS line convolutions
 constexpr int kLdsLimit = 160 * 1024;                // bytes of LDS a workgroup may use on gfx950
-constexpr int kRedFloats = 16 * (kSlabThreads / DPC_WAVE);
+constexpr int kRedFloats = 1024;  // reduction scratch (13 x 16 floats) + the record table at float offset 512
 constexpr int kLdsBudget = kLdsLimit - 4096;         // generic slab bytes; the rest holds the reduction scratch
 
 __device__ inline int odd_stride(int w) { return w | 1; }  // generic LDS row stride: odd => conflict-free column walks
@@ -76,8 +76,49 @@ struct Cells {
   }
 };
 
-// Visit every record of cloud b whose bin lies in [bin_lo, bin_hi): waves take chunks round-robin, lanes take
-// consecutive sorted positions.  f(rec, original_index).
+// Visit every record of cloud b whose bin lies in [bin_lo, bin_hi).  f(rec, original_index).
+//   build_record_table (wave 0, before a barrier the caller already has): lane c reads chunk c's range, an
+//   inclusive scan over lanes gives every chunk's first flat index; tab = {prefix[nblk+1], begin[nblk]} in LDS.
+//   for_each_record_flat: threads take flat indices tid, tid+nthr, ... and find their chunk by binary search in
+//   the table -- balanced over the whole workgroup and only two dependent global reads deep (offsets, record).
+// Needs nblk <= 64 (N <= 16384); larger clouds use the wave-per-chunk loop below.
+constexpr int kTabInts = 2 * DPC_WAVE + 2;
+
+__device__ inline void build_record_table(const Cells& cells, int b, int bin_lo, int bin_hi, int* tab) {
+  if (threadIdx.x >= DPC_WAVE) return;
+  const int c = threadIdx.x;
+  int beg = 0, cnt = 0;
+  if (c < cells.nblk) {
+    const uint16_t* offs = cells.offs(b, c);
+    beg = offs[bin_lo];
+    cnt = (int)offs[bin_hi] - beg;
+  }
+  int incl = cnt;
+#pragma unroll
+  for (int off = 1; off < DPC_WAVE; off <<= 1) {
+    const int up = __shfl_up(incl, off, DPC_WAVE);
+    if (c >= off) incl += up;
+  }
+  tab[c] = incl - cnt;               // exclusive prefix
+  tab[DPC_WAVE + 1 + c] = beg;
+  if (c == DPC_WAVE - 1) tab[DPC_WAVE] = incl;  // total
+}
+
+template <class F>
+__device__ inline void for_each_record_flat(const Cells& cells, int b, const int* tab, F f) {
+  const int total = tab[DPC_WAVE];
+  for (int j = threadIdx.x; j < total; j += blockDim.x) {
+    int lo = 0, hi = DPC_WAVE;  // largest c with tab[c] <= j (prefix is non-decreasing; empty chunks repeat values)
+#pragma unroll
+    for (int step = 0; step < 6; ++step) {
+      const int mid = (lo + hi) >> 1;
+      if (tab[mid] <= j) lo = mid; else hi = mid;
+    }
+    const int pos = tab[DPC_WAVE + 1 + lo] + (j - tab[lo]);
+    f(load_record(cells.recs(b, lo), pos), cells.perm(b, lo)[pos]);
+  }
+}
+
 template <class F>
 __device__ inline void for_each_record(const Cells& cells, int b, int bin_lo, int bin_hi, F f) {
   const int lane = threadIdx.x & (DPC_WAVE - 1), wave = threadIdx.x / DPC_WAVE, nw = blockDim.x / DPC_WAVE;
@@ -392,11 +433,13 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
     static_assert(VOX % Geo::NT == 0 && Geo::NT % 64 == 0 && (GS * GS) % 64 == 0, "slab shape");
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(slab);
     f32x4* s4 = reinterpret_cast<f32x4*>(slab);
+    int* tab = reinterpret_cast<int*>(slab + 2 * VOX);  // record table sits behind the accumulators
+    const bool flat = cells.nblk <= DPC_WAVE;
+    if (flat) build_record_table(cells, b, max(z0 - 1, 0), z0 + nz, tab);
     if (!DPC_ABL(0))
     for (int i = tid; i < VOX / 2; i += Geo::NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    if (!DPC_ABL(4))
-    for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, [&](const PointRec& rec, int) {
+    auto scatter = [&](const PointRec& rec, int) {
       const Cell c = cell_from_record(rec);
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -413,7 +456,11 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
           }
         }
       }
-    });
+    };
+    if (!DPC_ABL(4)) {
+      if (flat) for_each_record_flat(cells, b, tab, scatter);
+      else for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, scatter);
+    }
     __syncthreads();
     // accumulators -> fp32 (registers), clamp mask straight from the integers (raw <= 1  <=>  acc <= 2^44)
     float val[VPT];
@@ -878,6 +925,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     using Geo = BwdGeo<GS, RB>;
     constexpr int NPL = ZS + 1;
     red = slab + ((Geo::slab_floats(NPL) + 3) / 4) * 4;
+    if (cells.nblk <= DPC_WAVE) build_record_table(cells, b, z0, min(z0 + Zs, D), reinterpret_cast<int*>(red + 512));
     // planes -> LDS (16-byte global loads, 16-byte LDS stores); absent planes and the row pads are zeroed
     if (!DPC_ABL(11))
     for (int i = tid; i < NPL * GS * (GS / 4); i += Geo::NT) {
@@ -948,8 +996,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     if constexpr (GS > 0) return slab[BwdGeo<GS, RB>::at(zz, yy, xx)];
     else return slab[(zz * H + yy) * odd_stride(W) + xx];
   };
-  if (!DPC_ABL(10))
-  for_each_record(cells, b, z0, min(z0 + Zs, D), [&](const PointRec& rec, int i) {
+  auto gather = [&](const PointRec& rec, int i) {
     const Cell c = cell_from_record(rec);
     float cv[2][2][2];
 #pragma unroll
@@ -975,7 +1022,11 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     float dpx, dpy, dpz;
     project_point_bwd(cam, o, px, py, pz, dgz * (float)(D - 1), dgy * (float)(H - 1), dgx * (float)(W - 1), dpx, dpy, dpz, g);
     dcloud[3 * i + 0] = dpx; dcloud[3 * i + 1] = dpy; dcloud[3 * i + 2] = dpz;
-  });
+  };
+  if (!DPC_ABL(10)) {
+    if (GS > 0 && cells.nblk <= DPC_WAVE) for_each_record_flat(cells, b, reinterpret_cast<const int*>(red + 512), gather);
+    else for_each_record(cells, b, z0, min(z0 + Zs, D), gather);
+  }
   if (blockIdx.x == 0)
     for_each_record(cells, b, D, D + 1, [&](const PointRec&, int i) {
       dcloud[3 * i + 0] = 0.f; dcloud[3 * i + 1] = 0.f; dcloud[3 * i + 2] = 0.f;
@@ -1121,7 +1172,8 @@ template <int GS, int ZS, int RB>
 int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
                       uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, hipStream_t st) {
   using Geo = FwdGeo<GS, ZS, RB>;
-  constexpr size_t lds = std::max((size_t)ZS * GS * GS * sizeof(unsigned long long), Geo::slab_floats(ZS) * sizeof(float));
+  constexpr size_t lds = std::max((size_t)ZS * GS * GS * sizeof(unsigned long long) + kTabInts * sizeof(int),
+                                  Geo::slab_floats(ZS) * sizeof(float));
   static_assert(lds <= kLdsLimit, "forward slab does not fit LDS");
   auto kern = k_splat_hw<GS, ZS, RB>;
   int rc = set_lds(kern, lds);
