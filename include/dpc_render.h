@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DPC_ABI_VERSION 5
+#define DPC_ABI_VERSION 6
 #define DPC_MAX_TAPS 63 /* longest 1-D smoothing kernel accepted (pc_gauss_kernel_size) */
 
 enum {
@@ -81,7 +81,7 @@ size_t dpc_cells_bytes(const DpcParams* p);
  * from the oracle's fp64 tr_pc. */
 int dpc_locate(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, float* tr_pc,
                void* cells, void* stream);
-/* Scratch the fused entry points need (one grid-sized fp32 buffer + per-tile partial sums). */
+/* Scratch the fused BACKWARD entry points need (one grid-sized fp32 buffer + per-tile partial sums). */
 size_t dpc_workspace_bytes(const DpcParams* p);
 
 /* ---------------------------------------------------------------------------------------------------
@@ -95,16 +95,18 @@ size_t dpc_workspace_bytes(const DpcParams* p);
  *   tr_pc    [B,N,3] (z,y,x) | NULL
  *   cells    dpc_cells_bytes(p) bytes of binned point records (saved for backward)
  *   raw      [B,D,H,W] unclamped splat | NULL (not needed by the backward)
- *   smoothed [B,D,H,W] grid after clamp + Gaussian, BEFORE the occupancy scale (saved for backward;
- *            voxels = s ? clamp(s*smoothed,0,1) : smoothed)
+ *   grid_wh  [B,D,H,W] grid after clamp + the W and H passes of the Gaussian (saved for backward, which
+ *            recomputes the D pass in registers instead of reading a second grid)
+ *   smoothed [B,D,H,W] | NULL: grid after the full Gaussian, before the occupancy scale
+ *            (voxels = s ? clamp(s*smoothed,0,1) : smoothed); optional, the hot path does not write it
  *   mask     [B,D,words] uint64 clamp mask (saved for backward)
  *   proj     [B,H,W] silhouette, rows already flipped
  *   trans    [B,H,W] per-ray transmittance prod(1-y) (ray order, not flipped) | NULL; saves the backward a pass
  * ------------------------------------------------------------------------------------------------- */
 int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                     const float* s, const float* host_kern_xy, const float* host_kern_z, float* tr_pc,
-                    void* cells, float* raw, float* smoothed, uint64_t* mask, float* proj, float* trans,
-                    void* workspace, void* stream);
+                    void* cells, float* raw, float* grid_wh, float* smoothed, uint64_t* mask, float* proj,
+                    float* trans, void* stream);
 
 /* Hand-written backward of the chain above (the reference relies on autograd).
  *   dproj [B,H,W] gradient w.r.t. the (flipped) silhouette
@@ -114,7 +116,7 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
  *          was given); fully overwritten, needs no zeroing by the caller. */
 int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                     const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
-                    const float* smoothed, const uint64_t* mask, const float* trans /* from fwd, or NULL */,
+                    const float* grid_wh, const uint64_t* mask, const float* trans /* from fwd, or NULL */,
                     const float* dproj, float* dpc, float* dsmall, void* workspace, void* stream);
 
 /* The same chain with the caller's silhouette loss fused in: add_proj_loss /
@@ -123,15 +125,15 @@ int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const f
  * accumulates each cloud's sum of squared differences, a one-block finalize picks argmin over K (first minimum)
  * and writes loss = sum_s min_k sse / S.  In the backward dproj = 2 (proj - gt) / S * dloss is formed on the fly
  * (never stored) and losing candidates skip all work -- their gradients are exact zeros.
- *   fwd outputs: proj [B,H,W], trans [B,H,W], sse [B], loss [1], winner [B/K] int32 (+ tr_pc|NULL, cells, smoothed, mask)
+ *   fwd outputs: proj [B,H,W], trans [B,H,W], sse [B], loss [1], winner [B/K] int32 (+ tr_pc|NULL, cells, grid_wh, mask)
  *   bwd inputs : dloss = device scalar arriving at `loss` (NULL = 1) */
 int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                          const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt,
-                         int num_candidates, float* tr_pc, void* cells, float* smoothed, uint64_t* mask, float* proj,
-                         float* trans, float* sse, float* loss, int32_t* winner, void* workspace, void* stream);
+                         int num_candidates, float* tr_pc, void* cells, float* grid_wh, uint64_t* mask, float* proj,
+                         float* trans, float* sse, float* loss, int32_t* winner, void* stream);
 int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                          const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
-                         const float* smoothed, const uint64_t* mask, const float* proj, const float* trans,
+                         const float* grid_wh, const uint64_t* mask, const float* proj, const float* trans,
                          const float* gt, int num_candidates, const int32_t* winner, const float* dloss, float* dpc,
                          float* dsmall, void* workspace, void* stream);
 

@@ -709,7 +709,7 @@ __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_fwd(Dp
         const int zz = z + k - RB;
         if (zz >= 0 && zz < DD) v2 = fmaf(taps.w[k], c[zz], v2);
       }
-      out[(size_t)z * HW] = v2;
+      if (smoothed != nullptr) out[(size_t)z * HW] = v2;
       const float y = drc_clamp(rc, occupancy(rc, v2));
       if (z == 0) y0 = y;
       trans *= 1.0 - (double)y;
@@ -744,7 +744,7 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_fwd_dyn(DpcParams P, RayHo
           if (zz >= 0 && zz < D) v2 = fmaf(taps.w[k], col[(size_t)zz * HW], v2);
         }
       }
-      out[(size_t)z * HW] = v2;
+      if (smoothed != nullptr) out[(size_t)z * HW] = v2;
       const float y = drc_clamp(rc, occupancy(rc, v2));
       if (z == 0) y0 = y;
       trans *= 1.0 - (double)y;
@@ -784,11 +784,15 @@ __device__ inline void zcol_bwd_epilogue(float ds_acc, float* ds_part, float* ds
   if (blockIdx.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)threadIdx.x * gridDim.y + b] = 0.f;  // [col][B]
 }
 
+// Reads the grid saved by the forward slab kernel (after clamp + W/H passes), recomputes the forward D-pass in
+// registers (cheaper than having the forward write, and this kernel read, a second full grid), then DRC backward,
+// scale/clamp backward and the adjoint D-pass.
 template <int DD, int RB>
-__global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_bwd(DpcParams P, RayHost rh, const float* __restrict__ smoothed,
+__global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHost rh, const float* __restrict__ Tin,
                                                           const float* __restrict__ s,
                                                           const float* __restrict__ dproj, const float* __restrict__ proj,
-                                                          const float* __restrict__ trans_in, TapsT<RB> taps_adj,
+                                                          const float* __restrict__ trans_in, TapsT<RB> taps,
+                                                          TapsT<RB> taps_adj,
                                                           float* __restrict__ dT, float* __restrict__ ds_part,
                                                           float* __restrict__ dsmall, LossArgs la) {
   const int HW = P.H * P.W;
@@ -796,8 +800,8 @@ __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_bwd(Dp
   float ds_acc = 0.f;
   if (ray < HW && !cloud_loses(la, b)) {
     const RayConst rc = ray_const(rh, s, b);
-    const float* col = smoothed + (size_t)b * DD * HW + ray;
-    float c[DD];
+    const float* col = Tin + (size_t)b * DD * HW + ray;
+    float c[DD], d[DD];
 #pragma unroll
     for (int z = 0; z < DD; ++z) c[z] = col[(size_t)z * HW];
     float Tf;
@@ -807,44 +811,55 @@ __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_bwd(Dp
       double trans = 1.0;
 #pragma unroll
       for (int z = 0; z < DD; ++z) {
-        trans *= 1.0 - (double)drc_clamp(rc, occupancy(rc, c[z]));
-        if ((z & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+        float v2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * RB + 1; ++k) {
+          const int zz = z + k - RB;
+          if (zz >= 0 && zz < DD) v2 = fmaf(taps.w[k], c[zz], v2);
+        }
+        trans *= 1.0 - (double)drc_clamp(rc, occupancy(rc, v2));
+        if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
       Tf = (float)trans;
-      // Opaque to the optimiser: without it the clamped values and lane masks of all DD voxels computed for
-      // the transmittance are kept live for the loop below (CSE), which spills the column to scratch.
-#pragma unroll
-      for (int z = 0; z < DD; ++z) asm volatile("" : "+v"(c[z]));
     }
     const float g = ray_grad(P, la, dproj, proj, b, ray);
-#pragma unroll
-    for (int z = 0; z < DD; ++z) {
-      float term;
-      c[z] = drc_voxel_bwd(rc, c[z], g, Tf, z == 0, term);
-      ds_acc += term;
-      // keep the unrolled per-voxel chains from being interleaved across voxels (it spills the column)
-      if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-    }
     float* out = dT + (size_t)b * DD * HW + ray;
+    // streaming over z: forward taps -> d(v2) -> adjoint taps, RB voxels behind
 #pragma unroll
-    for (int z = 0; z < DD; ++z) {
-      float acc = 0.f;
+    for (int z = 0; z < DD + RB; ++z) {
+      if (z < DD) {
+        float v2 = 0.f;
 #pragma unroll
-      for (int k = 0; k < 2 * RB + 1; ++k) {
-        const int zz = z + k - RB;
-        if (zz >= 0 && zz < DD) acc = fmaf(taps_adj.w[k], c[zz], acc);
+        for (int k = 0; k < 2 * RB + 1; ++k) {
+          const int zz = z + k - RB;
+          if (zz >= 0 && zz < DD) v2 = fmaf(taps.w[k], c[zz], v2);
+        }
+        float term;
+        d[z] = drc_voxel_bwd(rc, v2, g, Tf, z == 0, term);
+        ds_acc += term;
       }
-      out[(size_t)z * HW] = acc;
+      if (z >= RB) {
+        const int zo = z - RB;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * RB + 1; ++k) {
+          const int zz = zo + k - RB;
+          if (zz >= 0 && zz < DD) acc = fmaf(taps_adj.w[k], d[zz], acc);
+        }
+        out[(size_t)zo * HW] = acc;
+      }
+      // keep the unrolled per-voxel chains from being interleaved across voxels (it would spill the columns)
       if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   }
   zcol_bwd_epilogue(ds_acc, ds_part, dsmall, b);
 }
 
-__global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHost rh, const float* __restrict__ smoothed,
+__global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHost rh, const float* __restrict__ Tin,
                                                               const float* __restrict__ s,
                                                               const float* __restrict__ dproj, const float* __restrict__ proj,
-                                                              const float* __restrict__ trans_in, TapsDyn taps_adj,
+                                                              const float* __restrict__ trans_in, TapsDyn taps,
+                                                              TapsDyn taps_adj,
                                                               float* __restrict__ dT, float* __restrict__ ds_part,
                                                               float* __restrict__ dsmall, LossArgs la) {
   const int HW = P.H * P.W, D = P.D;
@@ -852,21 +867,30 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHo
   float ds_acc = 0.f;
   if (ray < HW && !cloud_loses(la, b)) {
     const RayConst rc = ray_const(rh, s, b);
-    const float* col = smoothed + (size_t)b * D * HW + ray;
+    const float* col = Tin + (size_t)b * D * HW + ray;
+    const int R = taps.n > 0 ? (taps.n - 1) / 2 : 0;
+    auto v2_at = [&](int z) -> float {  // forward D-pass at depth z
+      if (taps.n == 0) return col[(size_t)z * HW];
+      float v2 = 0.f;
+      for (int k = 0; k < taps.n; ++k) {
+        const int zz = z + k - R;
+        if (zz >= 0 && zz < D) v2 = fmaf(taps.w[k], col[(size_t)zz * HW], v2);
+      }
+      return v2;
+    };
     float Tf;
     if (trans_in != nullptr) {
       Tf = trans_in[(size_t)b * HW + ray];
     } else {
       double trans = 1.0;
-      for (int z = 0; z < D; ++z) trans *= 1.0 - (double)drc_clamp(rc, occupancy(rc, col[(size_t)z * HW]));
+      for (int z = 0; z < D; ++z) trans *= 1.0 - (double)drc_clamp(rc, occupancy(rc, v2_at(z)));
       Tf = (float)trans;
     }
     const float g = ray_grad(P, la, dproj, proj, b, ray);
-    const int R = taps_adj.n > 0 ? (taps_adj.n - 1) / 2 : 0;
     float* out = dT + (size_t)b * D * HW + ray;
     for (int z = 0; z < D; ++z) {
       float term;
-      const float own = drc_voxel_bwd(rc, col[(size_t)z * HW], g, Tf, z == 0, term);
+      const float own = drc_voxel_bwd(rc, v2_at(z), g, Tf, z == 0, term);
       ds_acc += term;
       float acc;
       if (taps_adj.n == 0) {
@@ -877,7 +901,7 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHo
           const int zz = z + k - R;
           if (zz >= 0 && zz < D) {
             float unused;
-            acc = fmaf(taps_adj.w[k], drc_voxel_bwd(rc, col[(size_t)zz * HW], g, Tf, zz == 0, unused), acc);
+            acc = fmaf(taps_adj.w[k], drc_voxel_bwd(rc, v2_at(zz), g, Tf, zz == 0, unused), acc);
           }
         }
       }
@@ -1303,17 +1327,17 @@ namespace {
 
 int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, const float* s,
                      const float* host_kern_xy, const float* host_kern_z, float* tr_pc, void* cells, float* raw,
-                     float* smoothed, uint64_t* mask, float* proj, float* trans, const LossArgs& la, void* workspace,
+                     float* grid_wh, float* smoothed, uint64_t* mask, float* proj, float* trans, const LossArgs& la,
                      hipStream_t st) {
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
-  if (!q || !smoothed || !mask || !proj || !workspace) return DPC_ERR_NULL;
+  if (!q || !grid_wh || !mask || !proj) return DPC_ERR_NULL;
   if (p->N > 0 && p->B > 0 && (!pc || !cells)) return DPC_ERR_NULL;
   if ((p->taps_xy > 0 && !host_kern_xy) || (p->taps_z > 0 && !host_kern_z)) return DPC_ERR_NULL;
   if (p->B == 0) return DPC_OK;
   const TapPlan pxy = plan_taps(host_kern_xy, p->taps_xy), pz = plan_taps(host_kern_z, p->taps_z);
   if (pxy.bucket < 0) return DPC_ERR_TAPS;  // in-LDS passes need a radius bucket; caller composes the stage ops
-  float* Tbuf = static_cast<float*>(workspace);
+  float* Tbuf = grid_wh;
 
   if ((rc = launch_locate(p, 0, pc, q, t, f, tr_pc, cells, st)) != DPC_OK) return rc;
   const Cells cv = cells_view(p, cells);
@@ -1342,12 +1366,12 @@ int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const 
 }
 
 int project_bwd_impl(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, const float* s,
-                     const float* host_kern_xy, const float* host_kern_z, const void* cells, const float* smoothed,
+                     const float* host_kern_xy, const float* host_kern_z, const void* cells, const float* grid_wh,
                      const uint64_t* mask, const float* dproj, const float* proj, const float* trans, const LossArgs& la,
                      float* dpc, float* dsmall, void* workspace, hipStream_t st) {
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
-  if (!q || !smoothed || !mask || !dsmall || !workspace) return DPC_ERR_NULL;
+  if (!q || !grid_wh || !mask || !dsmall || !workspace) return DPC_ERR_NULL;
   if (la.gt == nullptr ? !dproj : (!proj || !la.winner)) return DPC_ERR_NULL;
   if (p->N > 0 && p->B > 0 && (!pc || !cells || !dpc)) return DPC_ERR_NULL;
   if ((p->taps_xy > 0 && !host_kern_xy) || (p->taps_z > 0 && !host_kern_z)) return DPC_ERR_NULL;
@@ -1364,16 +1388,17 @@ int project_bwd_impl(const DpcParams* p, const float* pc, const float* q, const 
   bool done = false;
 #define LAUNCH_ZBWD(RB)                                                                                           \
   {                                                                                                               \
-    const TapsT<RB> tz = make_taps<RB>(host_kern_z, pz, true);                                                    \
-    if (p->D == 32) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, proj, trans, tz, dT, ds_part, dsmall, la); done = true; } \
-    else if (p->D == 64) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, proj, trans, tz, dT, ds_part, dsmall, la); done = true; } \
-    else if (p->D == 128) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, proj, trans, tz, dT, ds_part, dsmall, la); done = true; } \
+    const TapsT<RB> tz = make_taps<RB>(host_kern_z, pz, true), tzf = make_taps<RB>(host_kern_z, pz, false);       \
+    if (p->D == 32) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, la); done = true; } \
+    else if (p->D == 64) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, la); done = true; } \
+    else if (p->D == 128) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, la); done = true; } \
   }
   if (pz.bucket >= 0) { DPC_FOR_BUCKET(pz.bucket, LAUNCH_ZBWD) }
 #undef LAUNCH_ZBWD
   if (!done) {
-    DPC_LAUNCH("k_zcol_bwd", k_zcol_bwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, smoothed, s, dproj, proj, trans,
-               make_taps_dyn(host_kern_z, p->taps_z, true), dT, ds_part, dsmall, la);
+    DPC_LAUNCH("k_zcol_bwd", k_zcol_bwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans,
+               make_taps_dyn(host_kern_z, p->taps_z, false), make_taps_dyn(host_kern_z, p->taps_z, true), dT, ds_part,
+               dsmall, la);
   }
   if ((rc = launch_ok()) != DPC_OK) return rc;
 
@@ -1393,33 +1418,32 @@ extern "C" {
 
 int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                     const float* s, const float* host_kern_xy, const float* host_kern_z, float* tr_pc, void* cells,
-                    float* raw, float* smoothed, uint64_t* mask, float* proj, float* trans, void* workspace,
-                    void* stream) {
-  return project_fwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, tr_pc, cells, raw, smoothed, mask, proj, trans,
-                          kNoLoss, workspace, (hipStream_t)stream);
+                    float* raw, float* grid_wh, float* smoothed, uint64_t* mask, float* proj, float* trans, void* stream) {
+  return project_fwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, tr_pc, cells, raw, grid_wh, smoothed, mask, proj,
+                          trans, kNoLoss, (hipStream_t)stream);
 }
 
 int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                     const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
-                    const float* smoothed, const uint64_t* mask, const float* trans, const float* dproj, float* dpc,
+                    const float* grid_wh, const uint64_t* mask, const float* trans, const float* dproj, float* dpc,
                     float* dsmall, void* workspace, void* stream) {
   if (!dproj) return DPC_ERR_NULL;
-  return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, smoothed, mask, dproj, nullptr, trans,
+  return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, grid_wh, mask, dproj, nullptr, trans,
                           kNoLoss, dpc, dsmall, workspace, (hipStream_t)stream);
 }
 
 int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                          const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt,
-                         int num_candidates, float* tr_pc, void* cells, float* smoothed, uint64_t* mask, float* proj,
-                         float* trans, float* sse, float* loss, int32_t* winner, void* workspace, void* stream) {
+                         int num_candidates, float* tr_pc, void* cells, float* grid_wh, uint64_t* mask, float* proj,
+                         float* trans, float* sse, float* loss, int32_t* winner, void* stream) {
   if (!p || !gt || !sse || !loss || !winner) return DPC_ERR_NULL;
   if (num_candidates < 1 || p->B % num_candidates != 0) return DPC_ERR_SHAPE;
   const int S = p->B / num_candidates;
   const bool direct = num_candidates == 1;  // every cloud is its sample's winner: blocks add straight into the loss
   const LossArgs la{gt, sse, nullptr, nullptr, num_candidates, S > 0 ? 1.0f / (float)S : 0.f,
                     direct ? loss : nullptr, direct ? winner : nullptr};
-  int rc = project_fwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, tr_pc, cells, nullptr, smoothed, mask, proj,
-                            trans, la, workspace, (hipStream_t)stream);
+  int rc = project_fwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, tr_pc, cells, nullptr, grid_wh, nullptr, mask,
+                            proj, trans, la, (hipStream_t)stream);
   if (rc != DPC_OK || p->B == 0 || direct) return rc;
   DPC_LAUNCH("k_loss_finalize", k_loss_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)sse, S,
              num_candidates, la.inv_S, loss, winner);
@@ -1428,14 +1452,14 @@ int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, co
 
 int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                          const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
-                         const float* smoothed, const uint64_t* mask, const float* proj, const float* trans,
+                         const float* grid_wh, const uint64_t* mask, const float* proj, const float* trans,
                          const float* gt, int num_candidates, const int32_t* winner, const float* dloss, float* dpc,
                          float* dsmall, void* workspace, void* stream) {
   if (!p || !gt || !winner || !proj) return DPC_ERR_NULL;
   if (num_candidates < 1 || p->B % num_candidates != 0) return DPC_ERR_SHAPE;
   const int S = p->B / num_candidates;
   const LossArgs la{gt, nullptr, winner, dloss, num_candidates, S > 0 ? 1.0f / (float)S : 0.f, nullptr, nullptr};
-  return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, smoothed, mask, nullptr, proj, trans, la,
+  return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, grid_wh, mask, nullptr, proj, trans, la,
                           dpc, dsmall, workspace, (hipStream_t)stream);
 }
 

@@ -283,7 +283,7 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation, 
     staged = lambda: _project_staged(cfg, geom, point_cloud, transform, predicted_translation, focal_length,
                                      scaling_factor, smooth)
     try:
-        proj, _ = ProjectFused.apply(point_cloud, transform, predicted_translation, focal_length, scaling_factor, geom)
+        proj = ProjectFused.apply(point_cloud, transform, predicted_translation, focal_length, scaling_factor, geom)
     except _native.DpcError as e:
         if e.code != _native.DPC_ERR_TAPS:
             raise

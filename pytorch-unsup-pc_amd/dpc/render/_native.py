@@ -12,7 +12,7 @@ import torch
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "csrc"))
 LIB_PATH = os.path.join(_CSRC, "libdpc_render.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 DPC_MAX_TAPS = 63
 DPC_SMALL_COLS = 12
 COL_DQ, COL_DS, COL_DT, COL_DF = 0, 4, 5, 8
@@ -70,7 +70,7 @@ def lib():
             fn.restype = ctypes.c_int
             fn.argtypes = [pp] + [vp] * nptr
         L.dpc_project_loss_fwd.restype = ctypes.c_int
-        L.dpc_project_loss_fwd.argtypes = [pp] + [vp] * 8 + [ctypes.c_int] + [vp] * 11
+        L.dpc_project_loss_fwd.argtypes = [pp] + [vp] * 8 + [ctypes.c_int] + [vp] * 10
         L.dpc_project_loss_bwd.restype = ctypes.c_int
         L.dpc_project_loss_bwd.argtypes = [pp] + [vp] * 13 + [ctypes.c_int] + [vp] * 6
         L.dpc_splat_fwd.restype = ctypes.c_int

@@ -107,10 +107,11 @@ def locate_points(pc, q, t, f, geom):
 # Fused hot path
 # ------------------------------------------------------------------------------------------------------
 class ProjectFused(torch.autograd.Function):
-    """pointcloud_project_fast as two launches forward, two backward (csrc/dpc_fused.hip).
+    """pointcloud_project_fast as three launches forward, two backward (csrc/dpc_fused.hip).
 
     forward(pc [B,N,3], q [B,4], t [B,3]|None, f [B,1]|None, s [B,1]|None, geom) -> proj [B,H,W,1]
-    ctx.smoothed ([B,D,H,W], pre-scale) is exposed for the lazily built `voxels` output.
+    Saved for backward: the binned point records, the grid after clamp + W/H passes, the clamp mask and the per-ray
+    transmittance.
     """
 
     @staticmethod
@@ -121,33 +122,31 @@ class ProjectFused(torch.autograd.Function):
         B, Npts = pc32.shape[0], pc32.shape[1]
         P = geom.params(B, Npts)
         wpp = L.dpc_mask_words_per_plane(ctypes.byref(P))
-        smoothed = torch.empty((B, geom.D, geom.H, geom.W), dtype=torch.float32, device=dev)
+        grid_wh = torch.empty((B, geom.D, geom.H, geom.W), dtype=torch.float32, device=dev)
         mask = torch.empty((B, geom.D, wpp), dtype=torch.int64, device=dev)
         cells = _new_cells(P, dev)
         proj = torch.empty((B, geom.H, geom.W, 1), dtype=torch.float32, device=dev)
         trans = torch.empty((B, geom.H, geom.W), dtype=torch.float32, device=dev)
-        ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
         kxy, kz = geom.kern_ptrs()
         with torch.cuda.device(dev):
             rc = L.dpc_project_fwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
-                                   None, N.ptr(cells), None, N.ptr(smoothed), N.ptr(mask), N.ptr(proj), N.ptr(trans),
-                                   N.ptr(ws), N.stream_ptr(dev))
+                                   None, N.ptr(cells), None, N.ptr(grid_wh), None, N.ptr(mask), N.ptr(proj), N.ptr(trans),
+                                   N.stream_ptr(dev))
         N.check(rc, "dpc_project_fwd")
         ctx.geom = geom
         ctx.inputs = tuple(_meta(x) for x in (pc, q, t, f, s))
-        ctx.save_for_backward(pc32, q32, t32 if t32 is not None else pc32.new_empty(0),
-                              f32 if f32 is not None else pc32.new_empty(0),
-                              s32 if s32 is not None else pc32.new_empty(0), smoothed, mask, cells, trans)
+        empty = pc32.new_empty(0)
+        ctx.save_for_backward(pc32, q32, t32 if t32 is not None else empty, f32 if f32 is not None else empty,
+                              s32 if s32 is not None else empty, grid_wh, mask, cells, trans)
         ctx.has = (t is not None, f is not None, s is not None)
         ctx.set_materialize_grads(False)
-        ctx.mark_non_differentiable(smoothed)
-        return proj, smoothed
+        return proj
 
     @staticmethod
-    def backward(ctx, dproj, _dsmoothed):
+    def backward(ctx, dproj):
         if dproj is None:
             return None, None, None, None, None, None
-        pc32, q32, t32, f32, s32, smoothed, mask, cells, trans = ctx.saved_tensors
+        pc32, q32, t32, f32, s32, grid_wh, mask, cells, trans = ctx.saved_tensors
         has_t, has_f, has_s = ctx.has
         t32 = t32 if has_t else None
         f32 = f32 if has_f else None
@@ -164,7 +163,7 @@ class ProjectFused(torch.autograd.Function):
         kxy, kz = geom.kern_ptrs()
         with torch.cuda.device(dev):
             rc = L.dpc_project_bwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
-                                   N.ptr(cells), N.ptr(smoothed), N.ptr(mask), N.ptr(trans), N.ptr(dproj32), N.ptr(dpc),
+                                   N.ptr(cells), N.ptr(grid_wh), N.ptr(mask), N.ptr(trans), N.ptr(dproj32), N.ptr(dpc),
                                    N.ptr(dsmall), N.ptr(ws), N.stream_ptr(dev))
         N.check(rc, "dpc_project_bwd")
         pc, q, t, f, s = ctx.inputs
@@ -199,23 +198,22 @@ class ProjectLossFused(torch.autograd.Function):
         P = geom.params(B, Npts)
         wpp = L.dpc_mask_words_per_plane(ctypes.byref(P))
         f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-        smoothed, proj, trans = f32e(B, geom.D, geom.H, geom.W), f32e(B, geom.H, geom.W, 1), f32e(B, geom.H, geom.W)
+        grid_wh, proj, trans = f32e(B, geom.D, geom.H, geom.W), f32e(B, geom.H, geom.W, 1), f32e(B, geom.H, geom.W)
         sse, loss = f32e(B), torch.empty((), dtype=torch.float32, device=dev)
         mask = torch.empty((B, geom.D, wpp), dtype=torch.int64, device=dev)
         winner = torch.empty((S,), dtype=torch.int32, device=dev)
         cells = _new_cells(P, dev)
-        ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
         kxy, kz = geom.kern_ptrs()
         with torch.cuda.device(dev):
             rc = L.dpc_project_loss_fwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
-                                        N.ptr(gt32), K, None, N.ptr(cells), N.ptr(smoothed), N.ptr(mask), N.ptr(proj),
-                                        N.ptr(trans), N.ptr(sse), N.ptr(loss), N.ptr(winner), N.ptr(ws), N.stream_ptr(dev))
+                                        N.ptr(gt32), K, None, N.ptr(cells), N.ptr(grid_wh), N.ptr(mask), N.ptr(proj),
+                                        N.ptr(trans), N.ptr(sse), N.ptr(loss), N.ptr(winner), N.stream_ptr(dev))
         N.check(rc, "dpc_project_loss_fwd")
         ctx.geom, ctx.K = geom, K
         ctx.inputs = tuple(_meta(x) for x in (pc, q, t, f, s))
         empty = pc32.new_empty(0)
         ctx.save_for_backward(pc32, q32, t32 if t32 is not None else empty, f32 if f32 is not None else empty,
-                              s32 if s32 is not None else empty, gt32, smoothed, mask, cells, proj, trans, winner)
+                              s32 if s32 is not None else empty, gt32, grid_wh, mask, cells, proj, trans, winner)
         ctx.has = (t is not None, f is not None, s is not None)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(proj, winner)
@@ -225,7 +223,7 @@ class ProjectLossFused(torch.autograd.Function):
     def backward(ctx, dloss, _dproj, _dwinner):
         if dloss is None:
             return (None,) * 8
-        pc32, q32, t32, f32, s32, gt32, smoothed, mask, cells, proj, trans, winner = ctx.saved_tensors
+        pc32, q32, t32, f32, s32, gt32, grid_wh, mask, cells, proj, trans, winner = ctx.saved_tensors
         has_t, has_f, has_s = ctx.has
         t32, f32, s32 = (t32 if has_t else None), (f32 if has_f else None), (s32 if has_s else None)
         geom, dev, L = ctx.geom, pc32.device, N.lib()
@@ -238,7 +236,7 @@ class ProjectLossFused(torch.autograd.Function):
         kxy, kz = geom.kern_ptrs()
         with torch.cuda.device(dev):
             rc = L.dpc_project_loss_bwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
-                                        N.ptr(cells), N.ptr(smoothed), N.ptr(mask), N.ptr(proj), N.ptr(trans), N.ptr(gt32),
+                                        N.ptr(cells), N.ptr(grid_wh), N.ptr(mask), N.ptr(proj), N.ptr(trans), N.ptr(gt32),
                                         ctx.K, N.ptr(winner), N.ptr(dl), N.ptr(dpc), N.ptr(dsmall), N.ptr(ws),
                                         N.stream_ptr(dev))
         N.check(rc, "dpc_project_loss_bwd")
