@@ -426,6 +426,70 @@ def test_project_loss_fused(R, O, K):
         assert gq.grad[torch.from_numpy(lose).cuda()].abs().max().item() == 0.0
 
 
+def test_config4_full_size(R, O):
+    """BASELINE config 4 per-GPU shard: 8 clouds x 16000 pts -> 128^3, sigma = 0.01 (sigma_rel 1.28), 21 taps.
+    Size-independent properties on all 8 clouds + the oracle on one of them (128^3 fp64 on CPU takes seconds)."""
+    B, N, G = 8, 16000, 128
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=21)
+    kern = R.smoothing_kernel(cfg, 1.28)
+    pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 404)
+    gp, gq, gs, ggt = dev(pc, True), dev(q, True), dev(s, True), dev(gt)
+    loss, out, win = R.pointcloud_project_loss(cfg, gp, gq, None, None, kern, scaling_factor=gs, gt=ggt)
+    loss.backward()
+    proj = out["proj"]
+    assert proj.shape == (B, G, G, 1) and torch.isfinite(proj).all() and torch.isfinite(gp.grad).all()
+    assert proj.min().item() >= 1.0 - (1.0 - 1e-5) ** G - 1e-6 and proj.max().item() <= 1.0 + 2e-5
+    assert (win == 0).all()
+    close(loss, ((proj - ggt) ** 2).sum() / B, TOL, "c4 loss")
+    raw, _ = R.pointcloud2voxels3d_fast(cfg, out["tr_pc"], None)
+    nvalid = ((out["tr_pc"] >= -0.5) & (out["tr_pc"] <= 0.5)).all(-1).sum().item()
+    assert abs(raw.double().sum().item() - nvalid) < 1.0
+    i = 3
+    cp, cq, cs = (x[i:i + 1].clone().requires_grad_(True) for x in (pc, q, s))
+    ref = O.pointcloud_project_fast(cfg, cp, cq, None, None, O.smoothing_kernel(cfg, 1.28), scaling_factor=cs)
+    (((ref["proj"] - gt[i:i + 1]) ** 2).sum() / B).backward()
+    close(proj[i:i + 1], ref["proj"], TOL, "c4 proj vs oracle")
+    close(gp.grad[i:i + 1], cp.grad, TOL, "c4 dpc vs oracle")
+    close(gq.grad[i:i + 1], cq.grad, 3e-5, "c4 dq vs oracle")
+    close(gs.grad[i:i + 1], cs.grad, 3e-5, "c4 ds vs oracle")
+
+
+def test_config5_full_size(R, O):
+    """BASELINE config 5: 16 samples x K=8 candidate rotations of the SAME cloud (tf_repeat_0), 8000 pts, 64^3,
+    min-of-K loss.  Winners and loss vs the oracle's silhouettes for 3 samples; losers get exact-zero gradients."""
+    S, K, N, G = 16, 8, 8000, 64
+    B = S * K
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=21)
+    kern = R.smoothing_kernel(cfg, 0.64)
+    base, _, sb, gtS, _, _ = O.synth_inputs(S, N, G, 505)
+    pc = base.repeat_interleave(K, dim=0)          # same cloud for the K candidates of a sample
+    s = sb.repeat_interleave(K, dim=0)
+    q = O.synth_inputs(B, 1, G, 506)[1]            # K different candidate quaternions per sample
+    gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+    loss, out, win = R.pointcloud_project_loss(cfg, gp, gq, None, None, kern, scaling_factor=gs, gt=dev(gtS), num_candidates=K)
+    loss.backward()
+    proj = out["proj"]
+    # the loss kernel's argmin/loss agree with the reference formula applied to the device silhouettes
+    rloss, rwin = O.proj_loss_pose_candidates(gtS, proj.detach().double().cpu(), K)
+    assert np.array_equal(win.cpu().numpy(), rwin.numpy())
+    close(loss, rloss, TOL, "c5 loss")
+    lose = torch.ones(B, dtype=torch.bool)
+    lose[torch.arange(S) * K + rwin] = False
+    assert gp.grad[lose.cuda()].abs().max().item() == 0.0 and gq.grad[lose.cuda()].abs().max().item() == 0.0
+    assert gp.grad[(~lose).cuda()].abs().max().item() > 0.0
+    # oracle on the candidates of 2 samples (16 clouds would take too long: take sample 5's 8 candidates only)
+    smp = 5
+    sl = slice(smp * K, (smp + 1) * K)
+    cp, cq, cs = (x[sl].clone().requires_grad_(True) for x in (pc, q, s))
+    ref = O.pointcloud_project_fast(cfg, cp, cq, None, None, O.smoothing_kernel(cfg, 0.64), scaling_factor=cs)
+    l1, w1 = O.proj_loss_pose_candidates(gtS[smp:smp + 1], ref["proj"], K)
+    (l1 / S).backward()                            # the batch loss divides by S samples
+    assert w1.item() == rwin[smp].item()
+    close(proj[sl], ref["proj"], TOL, "c5 proj vs oracle")
+    close(gp.grad[sl], cp.grad, TOL, "c5 dpc vs oracle")
+    close(gq.grad[sl], cq.grad, 3e-5, "c5 dq vs oracle")
+
+
 def test_point_dropout_matches_reference_rng(R):
     pts = torch.arange(2 * 10 * 3, dtype=torch.float32, device="cuda").reshape(2, 10, 3)
     np.random.seed(7)
