@@ -31,8 +31,12 @@ for p in (ROOT, os.path.join(ROOT, "pytorch-unsup-pc_amd")):
 import torch
 import torch.distributed as dist
 
-B, N_PTS, G, KSIZE, SIGMA_REL = 32, 8000, 64, 21, 0.64
+B, N_PTS, G, KSIZE, SIGMA_REL, K_CAND = 32, 8000, 64, 21, 0.64, 1   # BASELINE configs[1] ("c2"), the default workload
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# other BASELINE configs, for extra data points only (the contract metric is quoted on c2)
+CONFIGS = {"c2": (32, 8000, 64, 0.64, 1),     # B, N, G, sigma_rel, pose candidates
+           "c4": (8, 16000, 128, 1.28, 1),    # per-GPU shard of B=64 over 8 GPUs, sigma = 0.01
+           "c5": (128, 8000, 64, 0.64, 8)}    # 16 samples x 8 candidate rotations, min-of-K loss
 
 
 def algorithmic_bytes_per_cloud(n, g):
@@ -104,7 +108,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP graph replay")
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE config (default c2 = the metric's)")
     args = ap.parse_args()
+    global B, N_PTS, G, SIGMA_REL, K_CAND
+    B, N_PTS, G, SIGMA_REL, K_CAND = CONFIGS[args.config]
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -126,6 +133,11 @@ def main():
     cfg = Cfg(vox_size=G, pc_gauss_kernel_size=KSIZE)
     kern = R.smoothing_kernel(cfg, SIGMA_REL)
     pc, q, s, gt = make_inputs(device, 1234 + rank)
+    if K_CAND > 1:  # candidates of a sample share its cloud, scale and mask (tf_repeat_0); quaternions differ
+        S = B // K_CAND
+        pc = pc[:S].repeat_interleave(K_CAND, dim=0).contiguous()
+        s = s[:S].repeat_interleave(K_CAND, dim=0).contiguous()
+        gt = gt[:S].contiguous()
     pc.requires_grad_(True), q.requires_grad_(True), s.requires_grad_(True)
 
     one = torch.ones((), device=device)
@@ -133,8 +145,8 @@ def main():
     if B % ns:
         raise SystemExit("--streams must divide %d" % B)
     # per-stream shards (leaves of their own, so each shard's backward accumulates into its own .grad)
-    shards = [[x[i * (B // ns):(i + 1) * (B // ns)].detach().clone().requires_grad_(x.requires_grad) for x in (pc, q, s, gt)]
-              for i in range(ns)]
+    shards = [[x[i * (x.shape[0] // ns):(i + 1) * (x.shape[0] // ns)].detach().clone().requires_grad_(x.requires_grad)
+               for x in (pc, q, s, gt)] for i in range(ns)]
     extra = [torch.cuda.Stream(device) for _ in range(ns - 1)]
     share = torch.full((), 1.0 / ns, device=device)
 
@@ -142,7 +154,7 @@ def main():
         # projection + sum((proj-gt)^2)/B in one autograd node (loss folded into the ray-march kernels)
         if ns == 1:
             pc.grad = q.grad = s.grad = None
-            loss, _, _ = R.pointcloud_project_loss(cfg, pc, q, None, None, kern, scaling_factor=s, gt=gt)
+            loss, _, _ = R.pointcloud_project_loss(cfg, pc, q, None, None, kern, scaling_factor=s, gt=gt, num_candidates=K_CAND)
             loss.backward(gradient=one)  # preallocated d(loss)=1: no ones-fill launch per step
             return loss
         main = torch.cuda.current_stream(device)
@@ -152,7 +164,7 @@ def main():
             st.wait_stream(main)
             with torch.cuda.stream(st):
                 spc.grad = sq.grad = ss.grad = None
-                l, _, _ = R.pointcloud_project_loss(cfg, spc, sq, None, None, kern, scaling_factor=ss, gt=sgt)
+                l, _, _ = R.pointcloud_project_loss(cfg, spc, sq, None, None, kern, scaling_factor=ss, gt=sgt, num_candidates=K_CAND)
                 l.backward(gradient=share)  # each shard's loss is a mean over B/ns clouds
                 losses.append(l)
         for st in extra:
@@ -233,9 +245,11 @@ def main():
         "unit": "point-clouds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1] (c2): B=32 clouds x 8000 pts -> 64^3 grid, 21-tap Gaussian "
-                               "sigma_rel=0.64 (sigma=0.01), DRC silhouette 64x64 vs mean-pooled 128x128 mask, "
-                               "loss sum((proj-gt)^2)/B, backward to pc, q, s",
+        "config": {"workload": "BASELINE %s: B=%d clouds x %d pts -> %d^3 grid, 21-tap Gaussian sigma_rel=%g "
+                               "(sigma=0.01), DRC silhouette %dx%d vs mean-pooled %dx%d mask, %s, backward to pc, q, s"
+                               % ("configs[1] (c2)" if args.config == "c2" else args.config, B, N_PTS, G, SIGMA_REL, G, G,
+                                  2 * G, 2 * G, "loss sum((proj-gt)^2)/B" if K_CAND == 1 else
+                                  "min-of-%d pose-candidate loss" % K_CAND),
                    "clouds_per_gpu": B, "points": N_PTS, "grid": G, "taps": KSIZE, "sigma_rel": SIGMA_REL,
                    "launch": "eager" if graph is None else "hip-graph replay", "streams": ns,
                    "sharding": "clouds, no collective"},

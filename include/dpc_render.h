@@ -72,8 +72,8 @@ size_t dpc_mask_words_per_plane(const DpcParams* p);
 /* Binned point records written by the locate kernel and consumed by the slab kernels -- opaque to the caller,
  * dpc_cells_bytes(p) bytes, saved between forward and backward.  Per cloud, ceil(N/256) chunks; each chunk holds
  * its 256 points counting-sorted by z cell: 256 x {int32 code = iz<<20|iy<<10|ix or -1 (out of bounds), 3 x fp32
- * fractional weights encoded so that both r and 1-r keep fp32 relative precision}, 256 x int32 original point
- * index, (D+2) x uint16 bin offsets (padded to 16 bytes). */
+ * fractional weights encoded so that both r and 1-r keep fp32 relative precision}, 256 x {px, py, pz, int32
+ * original point index} sorted alike, (D+2) x uint16 bin offsets (padded to 16 bytes). */
 size_t dpc_cells_bytes(const DpcParams* p);
 /* First launch of the fused forward on its own: transform (the reference's exact op sequence, see
  * csrc/dpc_common.h) + cell location + per-256-point z sort.  tr_pc [B,N,3] | NULL, cells dpc_cells_bytes(p).

@@ -54,11 +54,11 @@ __device__ inline int odd_stride(int w) { return w | 1; }  // generic LDS row st
 // ------------------------------------------------------------------------------------------------------
 // Binned point storage ("cells"): per cloud, ceil(N/256) chunks; chunk c holds the records of points
 // [256c, 256c+256) counting-sorted by bin (bin = z cell iz, or D for out-of-bounds points):
-//   [256 x PointRec (16 B)] [256 x int32 original point index] [(D+2) x uint16 bin start offsets, padded to 16 B]
+//   [256 x PointRec (16 B)] [256 x {px, py, pz, original index} (16 B)] [(D+2) x uint16 bin start offsets, padded to 16 B]
 // offs[k] = first sorted position of bin k; offs[D+1] = number of points in the chunk.
 // ------------------------------------------------------------------------------------------------------
 __host__ __device__ inline size_t chunk_bytes(int D) {
-  return (size_t)kLocThreads * (sizeof(PointRec) + sizeof(int)) + (((size_t)(D + 2) * 2 + 15) / 16) * 16;
+  return (size_t)kLocThreads * 2 * sizeof(PointRec) + (((size_t)(D + 2) * 2 + 15) / 16) * 16;
 }
 __host__ __device__ inline int num_chunks(int N) { return (N + kLocThreads - 1) / kLocThreads; }
 
@@ -68,15 +68,16 @@ struct Cells {
   int nblk;       // chunks per cloud
   __device__ const uint8_t* at(int b, int blk) const { return base + ((size_t)b * nblk + blk) * chunk; }
   __device__ const PointRec* recs(int b, int blk) const { return reinterpret_cast<const PointRec*>(at(b, blk)); }
-  __device__ const int* perm(int b, int blk) const {
-    return reinterpret_cast<const int*>(at(b, blk) + (size_t)kLocThreads * sizeof(PointRec));
+  // the point itself and its original index, sorted like the records (the backward reads them sequentially)
+  __device__ const int4* aux(int b, int blk) const {
+    return reinterpret_cast<const int4*>(at(b, blk) + (size_t)kLocThreads * sizeof(PointRec));
   }
   __device__ const uint16_t* offs(int b, int blk) const {
-    return reinterpret_cast<const uint16_t*>(at(b, blk) + (size_t)kLocThreads * (sizeof(PointRec) + sizeof(int)));
+    return reinterpret_cast<const uint16_t*>(at(b, blk) + (size_t)kLocThreads * 2 * sizeof(PointRec));
   }
 };
 
-// Visit every record of cloud b whose bin lies in [bin_lo, bin_hi).  f(rec, original_index).
+// Visit every record of cloud b whose bin lies in [bin_lo, bin_hi).  f(rec, aux) with aux -> {px,py,pz,orig}.
 //   build_record_table (wave 0, before a barrier the caller already has): lane c reads chunk c's range, an
 //   inclusive scan over lanes gives every chunk's first flat index; tab = {prefix[nblk+1], begin[nblk]} in LDS.
 //   for_each_record_flat: threads take flat indices tid, tid+nthr, ... and find their chunk by binary search in
@@ -115,7 +116,7 @@ __device__ inline void for_each_record_flat(const Cells& cells, int b, const int
       if (tab[mid] <= j) lo = mid; else hi = mid;
     }
     const int pos = tab[DPC_WAVE + 1 + lo] + (j - tab[lo]);
-    f(load_record(cells.recs(b, lo), pos), cells.perm(b, lo)[pos]);
+    f(load_record(cells.recs(b, lo), pos), cells.aux(b, lo) + pos);
   }
 }
 
@@ -127,8 +128,8 @@ __device__ inline void for_each_record(const Cells& cells, int b, int bin_lo, in
     const int beg = __builtin_amdgcn_readfirstlane((int)offs[bin_lo]);
     const int end = __builtin_amdgcn_readfirstlane((int)offs[bin_hi]);
     const PointRec* recs = cells.recs(b, blk);
-    const int* perm = cells.perm(b, blk);
-    for (int j = beg + lane; j < end; j += DPC_WAVE) f(load_record(recs, j), perm[j]);
+    const int4* aux = cells.aux(b, blk);
+    for (int j = beg + lane; j < end; j += DPC_WAVE) f(load_record(recs, j), aux + j);
   }
 }
 
@@ -155,11 +156,13 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
 
   PointRec rec;
   rec.code = -1; rec.tz = rec.ty = rec.tx = 0.f;
+  float src_pt[3] = {0.f, 0.f, 0.f};  // the untransformed point (SRC 0), carried next to its record for the backward
   if (live) {
     const size_t idx = (size_t)b * P.N + i;
     double Z, Y, X;
     if (SRC == 0) {
       const float* p = static_cast<const float*>(pts) + idx * 3;
+      src_pt[0] = p[0]; src_pt[1] = p[1]; src_pt[2] = p[2];
       project_point_ref(cam_s, p[0], p[1], p[2], Z, Y, X);
       if (tr_pc != nullptr) {
         tr_pc[idx * 3 + 0] = (float)Z; tr_pc[idx * 3 + 1] = (float)Y; tr_pc[idx * 3 + 2] = (float)X;
@@ -199,16 +202,26 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
   }
   __syncthreads();
 
-  const size_t chunk = chunk_bytes(D);
-  uint8_t* out = cells_out + ((size_t)b * gridDim.x + blk) * chunk;
+  // sorted chunk staged in LDS, then copied out with one coalesced 16-byte store per lane and array
+  __shared__ int4 stage[2 * kLocThreads];
   if (live) {
     const int pos = hist[bin] + rank;
     int4 v;
     v.x = rec.code; v.y = __float_as_int(rec.tz); v.z = __float_as_int(rec.ty); v.w = __float_as_int(rec.tx);
-    reinterpret_cast<int4*>(out)[pos] = v;
-    reinterpret_cast<int*>(out + (size_t)kLocThreads * sizeof(PointRec))[pos] = i;
+    stage[pos] = v;
+    int4 a;
+    a.x = __float_as_int(src_pt[0]); a.y = __float_as_int(src_pt[1]); a.z = __float_as_int(src_pt[2]); a.w = i;
+    stage[kLocThreads + pos] = a;
   }
-  uint16_t* offs = reinterpret_cast<uint16_t*>(out + (size_t)kLocThreads * (sizeof(PointRec) + sizeof(int)));
+  __syncthreads();
+  const size_t chunk = chunk_bytes(D);
+  uint8_t* out = cells_out + ((size_t)b * gridDim.x + blk) * chunk;
+  const int npts = min(kLocThreads, P.N - blk * kLocThreads);
+  if (tid < npts) {
+    reinterpret_cast<int4*>(out)[tid] = stage[tid];
+    reinterpret_cast<int4*>(out + (size_t)kLocThreads * sizeof(PointRec))[tid] = stage[kLocThreads + tid];
+  }
+  uint16_t* offs = reinterpret_cast<uint16_t*>(out + (size_t)kLocThreads * 2 * sizeof(PointRec));
   for (int k = tid; k < nbins + 1; k += kLocThreads) offs[k] = (uint16_t)hist[k];
 }
 
@@ -291,9 +304,13 @@ struct SlabGeo {
 // forward: ZS planes, 16 voxels per thread, short segments so that every thread owns exactly one W and one H item
 template <int GS, int ZS, int RB>
 using FwdGeo = SlabGeo<GS, RB, ZS * GS * GS / 16, 16, 8>;
-// backward: ZS+1 planes (halo), long segments
-template <int GS, int RB>
-using BwdGeo = SlabGeo<GS, RB, (GS >= 64 ? 1024 : 256), 32, 16>;
+// backward: NPL = ZS+1 planes (halo), long segments; one item per thread up to 1024 threads
+constexpr int bwd_threads(int gs, int npl) {
+  const int items = npl * gs * (gs / 32);
+  return items >= 1024 ? 1024 : (items <= 256 ? 256 : ((items + 63) / 64) * 64);
+}
+template <int GS, int RB, int NPL>
+using BwdGeo = SlabGeo<GS, RB, bwd_threads(GS, NPL), 32, 16>;
 
 constexpr float kFixScale = 17592186044416.0f;          // 2^44: splat weights accumulate as 64-bit fixed point
 constexpr float kFixInv = 1.0f / 17592186044416.0f;
@@ -402,6 +419,40 @@ __device__ inline void hpass_fast(const float* slab, const TapsT<RB>& taps, Stor
   if (INPLACE) __syncthreads();
 }
 
+// The same H-pass with the input planes in GLOBAL memory ([planes][GS][GS], dense): used by the backward slab
+// kernel so that dT is read once, convolved in registers and written to LDS once.  Planes >= planes_present and rows
+// outside the plane read as zero.
+template <class Geo, int GS, int RB, int NPL, class Store>
+__device__ inline void hpass_global(const float* __restrict__ src, int planes_present, const TapsT<RB>& taps, Store store) {
+  constexpr int ITEMS = NPL * Geo::XP * Geo::NSEGH, IPT = (ITEMS + Geo::NT - 1) / Geo::NT;
+#pragma unroll
+  for (int it = 0; it < IPT; ++it) {
+    const int item = threadIdx.x + it * Geo::NT;
+    if (item < ITEMS) {
+      const int xp = item % Geo::XP, rest = item / Geo::XP;
+      const int z = rest % NPL, seg = rest / NPL;
+      const float* col = src + (size_t)z * GS * GS + 2 * xp;
+      const int y0 = seg * Geo::LH - RB;
+      const bool have = z < planes_present;
+      f32x2 v[Geo::HWIN];
+#pragma unroll
+      for (int i = 0; i < Geo::HWIN; ++i) {
+        const int y = y0 + i;
+        const bool in = have && !((i < RB && y < 0) || (i >= Geo::LH + RB && y >= GS));
+        v[i] = in ? *reinterpret_cast<const f32x2*>(col + (size_t)y * GS) : f32x2{0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < Geo::LH; ++j) {
+        f32x2 acc = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int tp = 0; tp < 2 * RB + 1; ++tp)
+          acc = __builtin_elementwise_fma(f32x2{taps.w[tp], taps.w[tp]}, v[j + tp], acc);
+        store(z, seg * Geo::LH + j, 2 * xp, acc);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Forward 1: splat + mask + clamp + W/H Gaussian passes.                          grid (nslab, B)
 //   GS = 0: generic (runtime dims, Zs = zs_rt);  GS > 0: specialised, ZS planes per slab.
@@ -439,7 +490,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
     if (!DPC_ABL(0))
     for (int i = tid; i < VOX / 2; i += Geo::NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
-    auto scatter = [&](const PointRec& rec, int) {
+    auto scatter = [&](const PointRec& rec, const int4*) {
       const Cell c = cell_from_record(rec);
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -511,7 +562,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
     const int WP = odd_stride(W);
     for (int i = tid; i < nz * H * WP; i += nthr) slab[i] = 0.f;
     __syncthreads();
-    for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, [&](const PointRec& rec, int) {
+    for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, [&](const PointRec& rec, const int4*) {
       const Cell c = cell_from_record(rec);
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
@@ -930,7 +981,10 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   const int b = blockIdx.y, z0 = blockIdx.x * Zs;
   if (cloud_loses(la, b)) {  // a losing pose candidate: zero gradient, no work (block-uniform)
     float* dz = dpc + (size_t)b * N * 3;
-    auto zero3 = [&](const PointRec&, int i) { dz[3 * i + 0] = 0.f; dz[3 * i + 1] = 0.f; dz[3 * i + 2] = 0.f; };
+    auto zero3 = [&](const PointRec&, const int4* aux) {
+      const int i = aux->w;
+      dz[3 * i + 0] = 0.f; dz[3 * i + 1] = 0.f; dz[3 * i + 2] = 0.f;
+    };
     for_each_record(cells, b, z0, min(z0 + Zs, D), zero3);
     if (blockIdx.x == 0) {
       for_each_record(cells, b, D, D + 1, zero3);
@@ -946,25 +1000,24 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   float* red;
 
   if constexpr (GS > 0) {
-    using Geo = BwdGeo<GS, RB>;
     constexpr int NPL = ZS + 1;
+    using Geo = BwdGeo<GS, RB, NPL>;
     red = slab + ((Geo::slab_floats(NPL) + 3) / 4) * 4;
     if (cells.nblk <= DPC_WAVE) build_record_table(cells, b, z0, min(z0 + Zs, D), reinterpret_cast<int*>(red + 512));
-    // planes -> LDS (16-byte global loads, 16-byte LDS stores); absent planes and the row pads are zeroed
-    if (!DPC_ABL(11))
-    for (int i = tid; i < NPL * GS * (GS / 4); i += Geo::NT) {
-      const int x4 = i % (GS / 4), zy = i / (GS / 4);
-      f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (zy < nzp * GS) val = *reinterpret_cast<const f32x4*>(src + (size_t)zy * GS + 4 * x4);
-      *reinterpret_cast<f32x4*>(slab + zy * Geo::WP + Geo::PAD + 4 * x4) = val;
-    }
-    for (int i = tid; i < (NPL * GS + 1) * (Geo::PAD / 4); i += Geo::NT) {
+    const uint32_t* mask32 = reinterpret_cast<const uint32_t*>(mrow);
+    for (int i = tid; i < (NPL * GS + 1) * (Geo::PAD / 4); i += Geo::NT) {  // zero the row pads (W-pass halo)
       const int p4 = i % (Geo::PAD / 4), row = i / (Geo::PAD / 4);
       *reinterpret_cast<f32x4*>(slab + row * Geo::WP + 4 * p4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();
-    const uint32_t* mask32 = reinterpret_cast<const uint32_t*>(mrow);
     if constexpr (RB == 0) {
+      // planes -> LDS (16-byte global loads, 16-byte LDS stores); absent planes are zeroed
+      for (int i = tid; i < NPL * GS * (GS / 4); i += Geo::NT) {
+        const int x4 = i % (GS / 4), zy = i / (GS / 4);
+        f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (zy < nzp * GS) val = *reinterpret_cast<const f32x4*>(src + (size_t)zy * GS + 4 * x4);
+        *reinterpret_cast<f32x4*>(slab + zy * Geo::WP + Geo::PAD + 4 * x4) = val;
+      }
+      __syncthreads();
       const float w2 = taps_adj.w[0] * taps_adj.w[0];
       for (int i = tid; i < NPL * GS * GS; i += Geo::NT) {
         const int x = i % GS, zy = i / GS;
@@ -974,11 +1027,12 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
       }
       __syncthreads();
     } else {
-      if (!DPC_ABL(8))
-      hpass_fast<Geo, GS, RB, NPL, true>(slab, taps_adj, [&](int z, int y, int x, f32x2 val) {
+      // adjoint H-pass with its windows read straight from global dT (lanes walk x: coalesced; the halo rows
+      // shared by neighbouring segments come from L1/L2), results stored to LDS once
+      hpass_global<Geo, GS, RB, NPL>(src, nzp, taps_adj, [&](int z, int y, int x, f32x2 val) {
         *reinterpret_cast<f32x2*>(slab + Geo::at(z, y, x)) = val;
       });
-      if (!DPC_ABL(9))
+      __syncthreads();
       wpass_fast<Geo, GS, RB, NPL, false, 2>(slab, taps_adj, const_cast<uint32_t*>(mask32), nzp);
     }
   } else {
@@ -1014,13 +1068,14 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   const Camera cam = load_camera(P, q, t, f, b);
   CamGrad g;
   camgrad_zero(g);
-  const float* cloud = pc + (size_t)b * N * 3;
   float* dcloud = dpc + (size_t)b * N * 3;
   auto corner = [&](int zz, int yy, int xx) -> float {
-    if constexpr (GS > 0) return slab[BwdGeo<GS, RB>::at(zz, yy, xx)];
+    if constexpr (GS > 0) return slab[BwdGeo<GS, RB, ZS + 1>::at(zz, yy, xx)];
     else return slab[(zz * H + yy) * odd_stride(W) + xx];
   };
-  auto gather = [&](const PointRec& rec, int i) {
+  auto gather = [&](const PointRec& rec, const int4* aux) {
+    const int4 pt = *aux;  // {px, py, pz, original index}: one 16-byte load, issued next to the record's
+    const int i = pt.w;
     const Cell c = cell_from_record(rec);
     float cv[2][2][2];
 #pragma unroll
@@ -1041,7 +1096,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
         dgy += (cv[a][1][e] - cv[a][0][e]) * c.wz[a] * c.wx[e];
         dgx += (cv[a][e][1] - cv[a][e][0]) * c.wz[a] * c.wy[e];
       }
-    const float px = cloud[3 * i + 0], py = cloud[3 * i + 1], pz = cloud[3 * i + 2];
+    const float px = __int_as_float(pt.x), py = __int_as_float(pt.y), pz = __int_as_float(pt.z);
     const Projected o = project_point(cam, px, py, pz);
     float dpx, dpy, dpz;
     project_point_bwd(cam, o, px, py, pz, dgz * (float)(D - 1), dgy * (float)(H - 1), dgx * (float)(W - 1), dpx, dpy, dpz, g);
@@ -1052,7 +1107,8 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     else for_each_record(cells, b, z0, min(z0 + Zs, D), gather);
   }
   if (blockIdx.x == 0)
-    for_each_record(cells, b, D, D + 1, [&](const PointRec&, int i) {
+    for_each_record(cells, b, D, D + 1, [&](const PointRec&, const int4* aux) {
+      const int i = aux->w;
       dcloud[3 * i + 0] = 0.f; dcloud[3 * i + 1] = 0.f; dcloud[3 * i + 2] = 0.f;
     });
 
@@ -1189,7 +1245,11 @@ Cells cells_view(const DpcParams* p, const void* cells) {
 #ifndef DPC_FWD_ZS64
 #define DPC_FWD_ZS64 4
 #endif
-constexpr int kFwdZs64 = DPC_FWD_ZS64;  // planes per forward slab at G = 64 (4 -> 1 workgroup/CU, 2 -> 2 workgroups/CU)
+constexpr int kFwdZs64 = DPC_FWD_ZS64;
+#ifndef DPC_BWD_ZS64
+#define DPC_BWD_ZS64 8
+#endif
+constexpr int kBwdZs64 = DPC_BWD_ZS64;  // cell layers per backward slab at G = 64 (8 -> 9 planes, 1 workgroup/CU; 3 -> 4 planes, 2/CU)  // planes per forward slab at G = 64 (4 -> 1 workgroup/CU, 2 -> 2 workgroups/CU)
 
 // ---- slab kernel dispatch: specialised when H = W in {32, 64, 128} and the padded slab fits, else generic
 template <int GS, int ZS, int RB>
@@ -1235,7 +1295,7 @@ template <int GS, int ZS, int RB>
 int launch_gather_fast(const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
                        const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask,
                        const float* ds_part, int ntile, float* dpc, float* dsmall, const LossArgs& la, hipStream_t st) {
-  using Geo = BwdGeo<GS, RB>;
+  using Geo = BwdGeo<GS, RB, ZS + 1>;
   constexpr size_t lds = (((Geo::slab_floats(ZS + 1) + 3) / 4) * 4 + kRedFloats) * sizeof(float);
   static_assert(lds <= kLdsLimit, "backward slab does not fit LDS");
   auto kern = k_gather_hw<GS, ZS, RB>;
@@ -1254,7 +1314,7 @@ int launch_gather(const DpcParams* p, Cells cells, const float* pc, const float*
     if constexpr (RB <= 4) {
       if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
       if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
-      if (p->H == 64) return launch_gather_fast<64, 8, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
+      if (p->H == 64) return launch_gather_fast<64, kBwdZs64, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
     } else if constexpr (RB <= 10) {
       if (p->H == 64) return launch_gather_fast<64, 7, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
     }

@@ -66,26 +66,30 @@ def _new_cells(P, dev):
 
 
 def decode_cells(cells, B, Npts, D):
-    """Test helper: binned point records -> (code [B,N] int32, frac [B,N,3] float32) in original point order."""
+    """Test helper: binned point records -> (code [B,N] int32, frac [B,N,3] float32, pts [B,N,3] float32) in
+    original point order; also checks each chunk's z sort and bin offsets."""
     nblk = (Npts + 255) // 256
-    chunk = 256 * 20 + ((2 * (D + 2) + 15) // 16) * 16
+    chunk = 256 * 32 + ((2 * (D + 2) + 15) // 16) * 16
     raw = cells.cpu().numpy().reshape(B, nblk, chunk)
     code = np.full((B, Npts), -2, dtype=np.int32)
     frac = np.zeros((B, Npts, 3), dtype=np.float32)
+    pts = np.zeros((B, Npts, 3), dtype=np.float32)
     for b in range(B):
         for k in range(nblk):
             n = min(256, Npts - 256 * k)
             rec = raw[b, k, :256 * 16].view(np.int32).reshape(256, 4)[:n]
-            perm = raw[b, k, 256 * 16:256 * 20].view(np.int32)[:n]
-            offs = raw[b, k, 256 * 20:256 * 20 + 2 * (D + 2)].view(np.uint16)
+            aux = raw[b, k, 256 * 16:256 * 32].view(np.int32).reshape(256, 4)[:n]
+            perm = aux[:, 3]
+            offs = raw[b, k, 256 * 32:256 * 32 + 2 * (D + 2)].view(np.uint16)
             assert offs[D + 1] == n and np.all(np.diff(offs.astype(np.int64)) >= 0)
             bins = np.where(rec[:, 0] < 0, D, rec[:, 0] >> 20)
             assert np.array_equal(np.sort(bins), bins), "records are not sorted by z bin"
             assert np.array_equal(np.searchsorted(bins, np.arange(D + 2)), offs), "bin offsets do not match the records"
             code[b, perm] = rec[:, 0]
             frac[b, perm] = rec[:, 1:].view(np.float32)
+            pts[b, perm] = aux[:, :3].view(np.float32)
     assert (code != -2).all(), "some points are missing from the bins"
-    return code, frac
+    return code, frac, pts
 
 
 def locate_points(pc, q, t, f, geom):

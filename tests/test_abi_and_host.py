@@ -47,7 +47,7 @@ def test_size_queries_and_validation_without_gpu():
     L = _native.lib()
     P = _native.DpcParams(32, 8000, 64, 64, 64, 21, 21, 2.0, 1.875, 1e-5, 10.0)
     assert L.dpc_mask_words_per_plane(ctypes.byref(P)) == 64
-    assert L.dpc_cells_bytes(ctypes.byref(P)) == 32 * 32 * (256 * 20 + 144)
+    assert L.dpc_cells_bytes(ctypes.byref(P)) == 32 * 32 * (256 * 32 + 144)
     ws = L.dpc_workspace_bytes(ctypes.byref(P))
     assert ws >= 32 * 64 ** 3 * 4 and ws % 256 == 0
     bad = _native.DpcParams(1, 10, 2048, 64, 64, 0, 0, 2.0, 1.875, 1e-5, 10.0)  # D beyond the 10-bit cell index

@@ -104,7 +104,8 @@ def test_locate_bit_exact(R, O, with_t, with_f):
     pc = pc * 1.3  # push ~10% of the points out of bounds
     tr_ref, code, enc = oracle_records(O, cfg, pc, q, t, f)
     tr, cells = locate_points(dev(pc), dev(q), dev(t), dev(f), _geometry(cfg))
-    got_code, got_enc = decode_cells(cells, 8, 8000, 64)  # also checks the per-chunk z sort and bin offsets
+    got_code, got_enc, got_pts = decode_cells(cells, 8, 8000, 64)  # also checks the per-chunk z sort and bin offsets
+    assert np.array_equal(got_pts, pc.numpy()), "points carried next to the records differ from the input cloud"
     assert np.array_equal(got_code, code), "cell index / validity differs for %d points" % (got_code != code).sum()
     assert np.array_equal(got_enc, enc), "encoded fractions differ"
     assert np.array_equal(tr.cpu().numpy(), tr_ref.astype(np.float32)), "tr_pc is not the fp32 rounding of the reference's"
