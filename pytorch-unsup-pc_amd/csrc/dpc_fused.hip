@@ -35,8 +35,17 @@
 __device__ int g_dpc_ablate = 0;  // diagnostic builds only: bit0 skip zero-fill, bit1 skip atomics, bit2 skip W, bit3 skip H
 extern "C" int dpc_debug_set_ablate(int v) { return hipMemcpyToSymbol(HIP_SYMBOL(g_dpc_ablate), &v, sizeof(int)) == hipSuccess ? 0 : -5; }
 #define DPC_ABL(bit) (g_dpc_ablate & (1 << (bit)))
+// per-phase timestamps (100 MHz s_memrealtime, comparable across CUs), thread 0 of every workgroup; 16 slots per block
+__device__ unsigned long long* g_dpc_stamps = nullptr;
+extern "C" int dpc_debug_set_stamps(void* p) { return hipMemcpyToSymbol(HIP_SYMBOL(g_dpc_stamps), &p, sizeof(void*)) == hipSuccess ? 0 : -5; }
+#define DPC_STAMP(slot)                                                                                    \
+  do {                                                                                                     \
+    if (g_dpc_stamps != nullptr && threadIdx.x == 0)                                                       \
+      g_dpc_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
 #else
 #define DPC_ABL(bit) 0
+#define DPC_STAMP(slot) do { } while (0)
 #endif
 
 namespace {
@@ -85,23 +94,33 @@ struct Cells {
 // Needs nblk <= 64 (N <= 16384); larger clouds use the wave-per-chunk loop below.
 constexpr int kTabInts = 2 * DPC_WAVE + 2;
 
-__device__ inline void build_record_table(const Cells& cells, int b, int bin_lo, int bin_hi, int* tab) {
+struct RecordRange {  // wave 0, lane c: sorted range [beg, beg+cnt) of chunk c
+  int beg, cnt;
+};
+
+// Issue the offset loads early (they are only waited for in finish_record_table, so a whole phase can run under them).
+__device__ inline RecordRange load_record_range(const Cells& cells, int b, int bin_lo, int bin_hi) {
+  RecordRange r{0, 0};
+  const int c = threadIdx.x;
+  if (c < DPC_WAVE && c < cells.nblk) {
+    const uint16_t* offs = cells.offs(b, c);
+    r.beg = offs[bin_lo];
+    r.cnt = (int)offs[bin_hi] - r.beg;
+  }
+  return r;
+}
+
+__device__ inline void finish_record_table(const RecordRange& r, int* tab) {
   if (threadIdx.x >= DPC_WAVE) return;
   const int c = threadIdx.x;
-  int beg = 0, cnt = 0;
-  if (c < cells.nblk) {
-    const uint16_t* offs = cells.offs(b, c);
-    beg = offs[bin_lo];
-    cnt = (int)offs[bin_hi] - beg;
-  }
-  int incl = cnt;
+  int incl = r.cnt;
 #pragma unroll
   for (int off = 1; off < DPC_WAVE; off <<= 1) {
     const int up = __shfl_up(incl, off, DPC_WAVE);
     if (c >= off) incl += up;
   }
-  tab[c] = incl - cnt;               // exclusive prefix
-  tab[DPC_WAVE + 1 + c] = beg;
+  tab[c] = incl - r.cnt;               // exclusive prefix
+  tab[DPC_WAVE + 1 + c] = r.beg;
   if (c == DPC_WAVE - 1) tab[DPC_WAVE] = incl;  // total
 }
 
@@ -318,8 +337,29 @@ constexpr unsigned long long kFixOne = 1ull << 44;
 
 // In-place W-pass over NPL planes.  MASK: 0 none, 1 emit the clamp mask from the raw values (forward),
 // 2 multiply the outputs by the stored mask bits (backward).  mask32 points at this slab's first plane.
+template <class Geo, int GS, int NPL>
+__host__ __device__ constexpr int wpass_items_per_thread() {
+  return (NPL * GS * Geo::NSEGW + Geo::NT - 1) / Geo::NT;
+}
+
+// Request the clamp-mask words of this thread's W-pass items ahead of time (MASK = 3 below consumes them).
+template <class Geo, int GS, int NPL>
+__device__ inline void wpass_mask_prefetch(const uint32_t* __restrict__ mask32, int planes_present,
+                                           uint32_t (&bits)[wpass_items_per_thread<Geo, GS, NPL>()]) {
+  constexpr int ROWS = NPL * GS, ITEMS = ROWS * Geo::NSEGW, IPT = wpass_items_per_thread<Geo, GS, NPL>();
+#pragma unroll
+  for (int it = 0; it < IPT; ++it) {
+    const int item = threadIdx.x + it * Geo::NT;
+    bits[it] = 0u;
+    if (item < ITEMS) {
+      const int row = item % ROWS, seg = item / ROWS;
+      if (row / GS < planes_present) bits[it] = mask32[(size_t)row * Geo::NSEGW + seg];
+    }
+  }
+}
+
 template <class Geo, int GS, int RB, int NPL, bool CLAMP1, int MASK>
-__device__ inline void wpass_fast(float* slab, const TapsT<RB>& taps, uint32_t* mask32, int planes_present) {
+__device__ inline void wpass_fast(float* slab, const TapsT<RB>& taps, const uint32_t* mask32, int planes_present) {
   constexpr int ROWS = NPL * GS, ITEMS = ROWS * Geo::NSEGW, IPT = (ITEMS + Geo::NT - 1) / Geo::NT;
   float v[IPT][Geo::LWIN];
 #pragma unroll
@@ -344,10 +384,9 @@ __device__ inline void wpass_fast(float* slab, const TapsT<RB>& taps, uint32_t* 
       const int z = row / GS;
       uint32_t bits = 0xffffffffu;
       static_assert(MASK != 1, "the forward emits its mask from the fixed-point accumulators");
-      if (MASK == 2) {  // LW outputs starting at x = seg*LW: bits of the row's mask words
-        static_assert(MASK != 2 || Geo::LW == 32, "mask word addressing assumes 32-output segments");
-        bits = z < planes_present ? mask32[(size_t)row * Geo::NSEGW + seg] : 0u;
-      }
+      static_assert(MASK == 0 || Geo::LW == 32, "mask word addressing assumes 32-output segments");
+      if (MASK == 2) bits = z < planes_present ? mask32[(size_t)row * Geo::NSEGW + seg] : 0u;  // bits of the row's mask word
+      if (MASK == 3) bits = mask32[it];  // prefetched by wpass_mask_prefetch (registers)
       if (CLAMP1) {
 #pragma unroll
         for (int k = 0; k < Geo::LWIN; ++k) v[it][k] = fminf(v[it][k], 1.0f);
@@ -362,7 +401,7 @@ __device__ inline void wpass_fast(float* slab, const TapsT<RB>& taps, uint32_t* 
           float acc = 0.f;
 #pragma unroll
           for (int tp = 0; tp < 2 * RB + 1; ++tp) acc = fmaf(taps.w[tp], v[it][j + tp + Geo::PAD - RB], acc);
-          o[e] = (MASK == 2 && !((bits >> j) & 1u)) ? 0.f : acc;
+          o[e] = (MASK >= 2 && !((bits >> j) & 1u)) ? 0.f : acc;
         }
         f32x4 q;
         q.x = o[0]; q.y = o[1]; q.z = o[2]; q.w = o[3];
@@ -479,17 +518,24 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
   if constexpr (GS > 0) {
     // Splat accumulation in 64-bit fixed point (2^-44): integer LDS atomics run ~9x faster than ds_add_f32 on
     // gfx950 (measured), the sums are exact to 6e-14 per contribution and independent of arrival order.
+    // Accumulator rows carry the same zero pads as the fp32 slab rows ([PAD][GS] u64), so the W-pass can take its
+    // windows straight from the accumulators.
     using Geo = FwdGeo<GS, ZS, RB>;
-    constexpr int VOX = ZS * GS * GS, VPT = VOX / Geo::NT;  // voxels per thread in the conversion pass
-    static_assert(VOX % Geo::NT == 0 && Geo::NT % 64 == 0 && (GS * GS) % 64 == 0, "slab shape");
+    constexpr int WPA = GS + Geo::PAD;                       // accumulator row stride (u64)
+    constexpr int ACC = ZS * GS * WPA + Geo::PAD;            // u64 words incl. the tail pad
+    constexpr int VOX = ZS * GS * GS, VPT = VOX / Geo::NT;
+    static_assert(VOX % Geo::NT == 0 && Geo::NT % 64 == 0 && (GS * GS) % 64 == 0 && ACC % 2 == 0, "slab shape");
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(slab);
     f32x4* s4 = reinterpret_cast<f32x4*>(slab);
-    int* tab = reinterpret_cast<int*>(slab + 2 * VOX);  // record table sits behind the accumulators
+    int* tab = reinterpret_cast<int*>(acc + ACC);            // record table sits behind the accumulators
     const bool flat = cells.nblk <= DPC_WAVE;
-    if (flat) build_record_table(cells, b, max(z0 - 1, 0), z0 + nz, tab);
-    if (!DPC_ABL(0))
-    for (int i = tid; i < VOX / 2; i += Geo::NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    DPC_STAMP(0);
+    RecordRange rr{0, 0};
+    if (flat) rr = load_record_range(cells, b, max(z0 - 1, 0), z0 + nz);  // in flight under the zero-fill
+    for (int i = tid; i < ACC / 2; i += Geo::NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (flat) finish_record_table(rr, tab);
     __syncthreads();
+    DPC_STAMP(1);
     auto scatter = [&](const PointRec& rec, const int4*) {
       const Cell c = cell_from_record(rec);
 #pragma unroll
@@ -503,60 +549,83 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
           for (int e = 0; e < 2; ++e) {
             if (c.ix + e >= GS) continue;
             const float w = c.wz[k] * c.wy[j] * c.wx[e];
-            atomicAdd(&acc[(zz * GS + c.iy + j) * GS + c.ix + e], (unsigned long long)(w * kFixScale));  // ds_add_u64
+            atomicAdd(&acc[(zz * GS + c.iy + j) * WPA + Geo::PAD + c.ix + e], (unsigned long long)(w * kFixScale));  // ds_add_u64
           }
         }
       }
     };
-    if (!DPC_ABL(4)) {
-      if (flat) for_each_record_flat(cells, b, tab, scatter);
-      else for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, scatter);
-    }
+    if (flat) for_each_record_flat(cells, b, tab, scatter);
+    else for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, scatter);
     __syncthreads();
-    // accumulators -> fp32 (registers), clamp mask straight from the integers (raw <= 1  <=>  acc <= 2^44)
-    float val[VPT];
+    DPC_STAMP(2);
+
     const size_t wpp = (HW + 63) / 64;
-    unsigned long long* mask_out = mask ? reinterpret_cast<unsigned long long*>(mask) + ((size_t)b * D + z0) * wpp : nullptr;
-    float* Tout = Tbuf ? Tbuf + ((size_t)b * D + z0) * HW : nullptr;
-#pragma unroll
-    for (int n = 0; n < VPT; ++n) {
-      const int i = tid + n * Geo::NT;  // lanes <-> consecutive x
-      const unsigned long long a = acc[i];
-      const unsigned long long bits = __ballot(a <= kFixOne);
-      const bool present = i < nz * GS * GS;
-      if (mask_out != nullptr && present && (tid & 63) == 0) mask_out[i >> 6] = bits;
-      // a < 2^56: hi < 2^24 converts exactly, lo rounds once, the fma rounds once more (<= 1 ulp overall)
-      const float v = fmaf((float)(unsigned)(a >> 32), 0x1p-12f, (float)(unsigned)a * kFixInv);
-      if (raw != nullptr && present) raw[((size_t)b * D + z0) * HW + i] = v;
-      val[n] = fminf(v, 1.0f);
-    }
-    if (Tbuf == nullptr) return;
-    if constexpr (RB == 0) {  // no smoothing (centre tap 1) or a kernel trimmed to its centre tap
-      const float w2 = taps.w[0] * taps.w[0];
+    // a < 2^56: hi < 2^24 converts exactly, lo rounds once, the fma rounds once more (<= 1 ulp overall)
+    auto to_float = [](unsigned long long a) {
+      return fmaf((float)(unsigned)(a >> 32), 0x1p-12f, (float)(unsigned)a * kFixInv);
+    };
+    if (Tbuf == nullptr || RB == 0) {
+      // stage-level splat (raw grid out) or no smoothing: plain conversion, lanes <-> consecutive x;
+      // clamp mask straight from the integers (raw <= 1  <=>  acc <= 2^44)
+      unsigned long long* mask_out = mask ? reinterpret_cast<unsigned long long*>(mask) + ((size_t)b * D + z0) * wpp : nullptr;
+      const float w2 = taps.w[0] * taps.w[0];  // centre tap of a kernel trimmed to radius 0 (1 when there is no kernel)
 #pragma unroll
       for (int n = 0; n < VPT; ++n) {
         const int i = tid + n * Geo::NT;
-        if (i < nz * GS * GS) Tout[i] = w2 * val[n];
+        const unsigned long long a = acc[(i / GS) * WPA + Geo::PAD + (i % GS)];
+        const unsigned long long bits = __ballot(a <= kFixOne);
+        const bool present = i < nz * GS * GS;
+        if (mask_out != nullptr && present && (tid & 63) == 0) mask_out[i >> 6] = bits;
+        const float v = to_float(a);
+        if (raw != nullptr && present) raw[((size_t)b * D + z0) * HW + i] = v;
+        if (Tbuf != nullptr && present) Tbuf[((size_t)b * D + z0) * HW + i] = w2 * fminf(v, 1.0f);
       }
       return;
     } else {
-      __syncthreads();  // every accumulator has been read: the same LDS now takes the padded fp32 slab
+      // W-pass with its windows converted on the fly from the accumulators; every thread owns one (row, segment)
+      constexpr int ROWS = ZS * GS;
+      static_assert(ROWS * Geo::NSEGW == Geo::NT && Geo::LW == 16, "one W item per thread, 16-bit mask pieces");
+      const int row = tid % ROWS, seg = tid / ROWS;
+      float v[Geo::LWIN];
+      unsigned bits = 0u;
+      {
+        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(acc + row * WPA + seg * Geo::LW);
 #pragma unroll
-      for (int n = 0; n < VPT; ++n) {
-        const int i = tid + n * Geo::NT;
-        slab[(i / GS) * Geo::WP + Geo::PAD + (i % GS)] = val[n];
+        for (int k = 0; k < Geo::LWIN / 2; ++k) {
+          const ulonglong2 q2 = src[k];
+          const unsigned long long a2[2] = {q2.x, q2.y};
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const int idx = 2 * k + e;
+            if (idx >= Geo::PAD && idx < Geo::PAD + Geo::LW) bits |= (a2[e] <= kFixOne ? 1u : 0u) << (idx - Geo::PAD);
+            v[idx] = fminf(to_float(a2[e]), 1.0f);
+          }
+        }
       }
-      for (int i = tid; i < (ZS * GS + 1) * (Geo::PAD / 4); i += Geo::NT) {  // zero row pads (and the tail pad)
-        const int p4 = i % (Geo::PAD / 4), row = i / (Geo::PAD / 4);
-        *reinterpret_cast<f32x4*>(slab + row * Geo::WP + 4 * p4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (row / GS < nz)  // this thread's 16 voxels of the clamp mask
+        reinterpret_cast<unsigned short*>(mask + ((size_t)b * D + z0) * wpp)[row * Geo::NSEGW + seg] = (unsigned short)bits;
+      __syncthreads();  // every accumulator has been read: the same LDS now takes the padded fp32 slab
+      DPC_STAMP(3);
+      f32x4* dst = reinterpret_cast<f32x4*>(slab + row * Geo::WP + Geo::PAD + seg * Geo::LW);
+#pragma unroll
+      for (int k = 0; k < Geo::LW / 4; ++k) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float accv = 0.f;
+#pragma unroll
+          for (int tp = 0; tp < 2 * RB + 1; ++tp) accv = fmaf(taps.w[tp], v[4 * k + e + tp + Geo::PAD - RB], accv);
+          o[e] = accv;
+        }
+        dst[k] = f32x4{o[0], o[1], o[2], o[3]};
       }
       __syncthreads();
-      if (!DPC_ABL(2))
-      wpass_fast<Geo, GS, RB, ZS, false, 0>(slab, taps, nullptr, nz);
-      if (!DPC_ABL(3))
+      DPC_STAMP(4);
+      float* Tout = Tbuf + ((size_t)b * D + z0) * HW;
       hpass_fast<Geo, GS, RB, ZS, false>(slab, taps, [&](int z, int y, int x, f32x2 v2) {
         if (z < nz) *reinterpret_cast<f32x2*>(Tout + ((size_t)z * GS + y) * GS + x) = v2;
       });
+      DPC_STAMP(5);
     }
   } else {
     const int WP = odd_stride(W);
@@ -1003,8 +1072,10 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     constexpr int NPL = ZS + 1;
     using Geo = BwdGeo<GS, RB, NPL>;
     red = slab + ((Geo::slab_floats(NPL) + 3) / 4) * 4;
-    if (cells.nblk <= DPC_WAVE) build_record_table(cells, b, z0, min(z0 + Zs, D), reinterpret_cast<int*>(red + 512));
+    RecordRange rr{0, 0};
+    if (cells.nblk <= DPC_WAVE) rr = load_record_range(cells, b, z0, min(z0 + Zs, D));  // in flight under the H-pass
     const uint32_t* mask32 = reinterpret_cast<const uint32_t*>(mrow);
+    DPC_STAMP(8);
     for (int i = tid; i < (NPL * GS + 1) * (Geo::PAD / 4); i += Geo::NT) {  // zero the row pads (W-pass halo)
       const int p4 = i % (Geo::PAD / 4), row = i / (Geo::PAD / 4);
       *reinterpret_cast<f32x4*>(slab + row * Geo::WP + 4 * p4) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1017,6 +1088,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
         if (zy < nzp * GS) val = *reinterpret_cast<const f32x4*>(src + (size_t)zy * GS + 4 * x4);
         *reinterpret_cast<f32x4*>(slab + zy * Geo::WP + Geo::PAD + 4 * x4) = val;
       }
+      if (cells.nblk <= DPC_WAVE) finish_record_table(rr, reinterpret_cast<int*>(red + 512));
       __syncthreads();
       const float w2 = taps_adj.w[0] * taps_adj.w[0];
       for (int i = tid; i < NPL * GS * GS; i += Geo::NT) {
@@ -1029,11 +1101,16 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     } else {
       // adjoint H-pass with its windows read straight from global dT (lanes walk x: coalesced; the halo rows
       // shared by neighbouring segments come from L1/L2), results stored to LDS once
+      uint32_t mbits[wpass_items_per_thread<Geo, GS, NPL>()];
+      wpass_mask_prefetch<Geo, GS, NPL>(mask32, nzp, mbits);  // mask words requested now, consumed after the H-pass
       hpass_global<Geo, GS, RB, NPL>(src, nzp, taps_adj, [&](int z, int y, int x, f32x2 val) {
         *reinterpret_cast<f32x2*>(slab + Geo::at(z, y, x)) = val;
       });
+      if (cells.nblk <= DPC_WAVE) finish_record_table(rr, reinterpret_cast<int*>(red + 512));
       __syncthreads();
-      wpass_fast<Geo, GS, RB, NPL, false, 2>(slab, taps_adj, const_cast<uint32_t*>(mask32), nzp);
+      DPC_STAMP(9);
+      wpass_fast<Geo, GS, RB, NPL, false, 3>(slab, taps_adj, mbits, nzp);
+      DPC_STAMP(10);
     }
   } else {
     const int WP = odd_stride(W);
@@ -1106,6 +1183,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     if (GS > 0 && cells.nblk <= DPC_WAVE) for_each_record_flat(cells, b, reinterpret_cast<const int*>(red + 512), gather);
     else for_each_record(cells, b, z0, min(z0 + Zs, D), gather);
   }
+  DPC_STAMP(11);
   if (blockIdx.x == 0)
     for_each_record(cells, b, D, D + 1, [&](const PointRec&, const int4* aux) {
       const int i = aux->w;
@@ -1118,6 +1196,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   vals[9] = g.dt[0]; vals[10] = g.dt[1]; vals[11] = g.dt[2]; vals[12] = g.df;
   if (DPC_ABL(13)) { if (vals[0] == 123.f) dsmall[0] = vals[1]; return; }
   block_sum<13>(vals, red);
+  DPC_STAMP(12);
   if (DPC_ABL(14)) { if (vals[0] == 123.f) dsmall[0] = vals[1]; return; }
   if (tid == 0) {
     float dq[4];
@@ -1136,6 +1215,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
       dsmall[(size_t)DPC_COL_DS * P.B + b] = ds;
     }
   }
+  DPC_STAMP(13);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1256,8 +1336,8 @@ template <int GS, int ZS, int RB>
 int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
                       uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, hipStream_t st) {
   using Geo = FwdGeo<GS, ZS, RB>;
-  constexpr size_t lds = std::max((size_t)ZS * GS * GS * sizeof(unsigned long long) + kTabInts * sizeof(int),
-                                  Geo::slab_floats(ZS) * sizeof(float));
+  constexpr size_t lds = ((size_t)ZS * GS * (GS + Geo::PAD) + Geo::PAD) * sizeof(unsigned long long) + kTabInts * sizeof(int);
+  static_assert(lds >= Geo::slab_floats(ZS) * sizeof(float), "the fp32 slab reuses the accumulator memory");
   static_assert(lds <= kLdsLimit, "forward slab does not fit LDS");
   auto kern = k_splat_hw<GS, ZS, RB>;
   int rc = set_lds(kern, lds);
