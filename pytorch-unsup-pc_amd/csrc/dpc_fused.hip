@@ -164,14 +164,14 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
                                                         const float* __restrict__ f, float* __restrict__ tr_pc,
                                                         uint8_t* __restrict__ cells_out) {
   __shared__ int hist[1026];  // D + 2 <= 1026 bins (validate() caps D at 1024)
-  __shared__ CameraRef cam_s;
   const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
   const int D = P.D, nbins = D + 1;
   const int i = blk * kLocThreads + tid;
   const bool live = i < P.N;
   for (int k = tid; k < nbins + 1; k += kLocThreads) hist[k] = 0;
-  if (SRC == 0 && tid == 0) cam_s = load_camera_ref(P, q, t, f, b);  // one normalisation per block
-  __syncthreads();
+  // every thread normalises the quaternion itself (a dozen fp32 ops): cheaper than one thread doing it while 255 wait
+  CameraRef cam_s;
+  if (SRC == 0) cam_s = load_camera_ref(P, q, t, f, b);
 
   PointRec rec;
   rec.code = -1; rec.tz = rec.ty = rec.tx = 0.f;
@@ -196,6 +196,7 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
     rec = make_record(Z, Y, X, P.D, P.H, P.W);
   }
   const int bin = rec.code < 0 ? D : (rec.code >> 20);
+  __syncthreads();  // hist is zeroed (the transform above ran under that latency)
   int rank = 0;
   if (live) rank = atomicAdd(&hist[bin], 1);  // ds_add_rtn_u32: position inside the bin
   __syncthreads();
