@@ -189,6 +189,9 @@ int dpc_profile_enable(int capacity);
 int dpc_profile_disable(void);
 int dpc_profile_count(void);
 int dpc_profile_get(int i, const char** name, float* ms);
+/* What an EMPTY begin/end event pair reads on `stream` (synchronising; call outside timed regions): subtract it from
+ * dpc_profile_get's figures to compare with rocprofv3's kernel durations. */
+int dpc_profile_pair_overhead(void* stream, int pairs, float* ms);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,28 @@ int dpc_profile_disable(void) {
 
 int dpc_profile_count(void) { return (int)g_used; }
 
+// Milliseconds an EMPTY begin/end event pair reads on `stream`: the floor every bracketed launch carries.
+int dpc_profile_pair_overhead(void* stream, int pairs, float* ms) {
+  if (!ms || pairs < 1) return DPC_ERR_SHAPE;
+  hipStream_t st = (hipStream_t)stream;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return DPC_ERR_LAUNCH;
+  float tot = 0.f;
+  int ok = 0;
+  for (int i = 0; i < pairs; ++i) {
+    (void)hipEventRecord(a, st);
+    (void)hipEventRecord(b, st);
+    if (hipEventSynchronize(b) != hipSuccess) break;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, a, b) == hipSuccess) { tot += t; ++ok; }
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  if (!ok) return DPC_ERR_LAUNCH;
+  *ms = tot / (float)ok;
+  return DPC_OK;
+}
+
 int dpc_profile_get(int i, const char** name, float* ms) {
   if (i < 0 || (size_t)i >= g_used || !name || !ms) return DPC_ERR_SHAPE;
   *name = g_slots[i].name;

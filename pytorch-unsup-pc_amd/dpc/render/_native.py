@@ -24,7 +24,7 @@ SYMBOLS = (
     "dpc_abi_version", "dpc_strerror", "dpc_mask_words_per_plane", "dpc_cells_bytes", "dpc_workspace_bytes", "dpc_locate",
     "dpc_project_fwd", "dpc_project_bwd", "dpc_project_loss_fwd", "dpc_project_loss_bwd", "dpc_transform_fwd", "dpc_transform_bwd",
     "dpc_splat_fwd", "dpc_splat_bwd", "dpc_smooth", "dpc_drc_fwd", "dpc_drc_bwd",
-    "dpc_silhouette_loss", "dpc_profile_enable", "dpc_profile_disable", "dpc_profile_count", "dpc_profile_get",
+    "dpc_silhouette_loss", "dpc_profile_enable", "dpc_profile_disable", "dpc_profile_count", "dpc_profile_get", "dpc_profile_pair_overhead",
 )
 
 
@@ -83,6 +83,8 @@ def lib():
         L.dpc_profile_count.restype = ctypes.c_int
         L.dpc_profile_get.restype = ctypes.c_int
         L.dpc_profile_get.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_float)]
+        L.dpc_profile_pair_overhead.restype = ctypes.c_int
+        L.dpc_profile_pair_overhead.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.dpc_silhouette_loss.restype = ctypes.c_int
         L.dpc_silhouette_loss.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
         L.dpc_smooth.restype = ctypes.c_int
@@ -133,6 +135,14 @@ def require_device(*tensors):
         elif t.device != dev:
             raise RuntimeError("dpc.render: tensors on different devices (%s vs %s)" % (dev, t.device))
     return dev
+
+
+def event_pair_overhead_ms(device, pairs=200):
+    """What an empty event pair reads on the current stream (the floor in every profile_kernels figure)."""
+    ms = ctypes.c_float()
+    torch.cuda.synchronize(device)
+    check(lib().dpc_profile_pair_overhead(stream_ptr(device), pairs, ctypes.byref(ms)), "dpc_profile_pair_overhead")
+    return ms.value
 
 
 def profile_kernels(fn, device, capacity=4096):
