@@ -491,6 +491,72 @@ def test_config5_full_size(R, O):
     close(gq.grad[sl], cq.grad, 3e-5, "c5 dq vs oracle")
 
 
+def test_many_chunks_fallback_iteration(R, O):
+    """N > 16384 points = more than 64 sorted chunks per cloud: the slab kernels take the wave-per-chunk loop."""
+    B, N, G = 2, 20000, 32
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 808)
+    leaf = lambda x: x.clone().requires_grad_(True)
+    cp, cq, cs = leaf(pc), leaf(q), leaf(s)
+    ref = O.pointcloud_project_fast(cfg, cp, cq, None, None, O.smoothing_kernel(cfg, 1.0), scaling_factor=cs)
+    (((ref["proj"] - gt) ** 2).sum() / B).backward()
+    gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+    out = R.pointcloud_project_fast(cfg, gp, gq, None, None, R.smoothing_kernel(cfg, 1.0), scaling_factor=gs)
+    (((out["proj"] - dev(gt)) ** 2).sum() / B).backward()
+    close(out["proj"], ref["proj"], TOL, "proj (N=20000)")
+    close(gp.grad, cp.grad, TOL, "dpc (N=20000)")
+    close(gq.grad, cq.grad, 1e-4, "dq (N=20000)")  # a sum over 20000 points in fp32
+    close(gs.grad, cs.grad, 3e-5, "ds (N=20000)")
+
+
+def test_empty_clouds_through_fused_path(R, O):
+    cfg = O.Cfg(vox_size=32, pc_gauss_kernel_size=11)
+    pc = torch.zeros(2, 0, 3, device="cuda", requires_grad=True)
+    q = torch.ones(2, 4, device="cuda", requires_grad=True)
+    s = torch.ones(2, 1, device="cuda", requires_grad=True)
+    out = R.pointcloud_project_fast(cfg, pc, q, None, None, R.smoothing_kernel(cfg, 1.0), scaling_factor=s)
+    empty = 1.0 - (1.0 - 1e-5) ** 32
+    assert out["proj"].shape == (2, 32, 32, 1) and abs(out["proj"].max().item() - empty) < 1e-7
+    out["proj"].sum().backward()
+    assert pc.grad.shape == (2, 0, 3) and q.grad.abs().max().item() == 0.0 and s.grad.abs().max().item() == 0.0
+
+
+def test_optional_outputs_of_the_c_abi(R, O, golden):
+    """dpc_project_fwd called directly: the optional `tr_pc`, `raw` (unclamped splat) and `smoothed` (grid after the
+    full Gaussian) outputs against the golden chain, and grid_wh == W/H-smoothed clamp(raw) via the stage kernels."""
+    import ctypes
+    from dpc.render import _native as N, _geometry
+    from dpc.render._ops import _new_cells
+
+    g = golden("f6_chain_g32.npz")
+    cfg = O.Cfg(vox_size=32, pc_gauss_kernel_size=11)
+    geom = _geometry(cfg, R.smoothing_kernel(cfg, float(g["sigma_rel"])))
+    pc, q, s = dev(g["pc"]), dev(g["q"]), dev(g["s"])
+    B, Np, G = pc.shape[0], pc.shape[1], 32
+    P = geom.params(B, Np)
+    L = N.lib()
+    f = lambda *sh: torch.empty(sh, dtype=torch.float32, device="cuda")
+    tr, raw, wh, sm, proj, trans = f(B, Np, 3), f(B, G, G, G), f(B, G, G, G), f(B, G, G, G), f(B, G, G), f(B, G, G)
+    mask = torch.empty((B, G, L.dpc_mask_words_per_plane(ctypes.byref(P))), dtype=torch.int64, device="cuda")
+    cells = _new_cells(P, pc.device)
+    kxy, kz = geom.kern_ptrs()
+    rc = L.dpc_project_fwd(ctypes.byref(P), N.ptr(pc), N.ptr(q), None, None, N.ptr(s), kxy, kz, N.ptr(tr), N.ptr(cells),
+                           N.ptr(raw), N.ptr(wh), N.ptr(sm), N.ptr(mask), N.ptr(proj), N.ptr(trans), N.stream_ptr(pc.device))
+    assert rc == 0
+    torch.cuda.synchronize()
+    close(tr, g["smooth_tr_pc"], 2e-6, "tr_pc (C ABI)")
+    close(raw.unsqueeze(1), g["smooth_raw"], TOL, "raw (C ABI)")
+    close(proj.unsqueeze(-1), g["smooth_proj"], TOL, "proj (C ABI)")
+    vox = torch.clamp(sm * s.reshape(-1, 1, 1, 1), 0.0, 1.0)
+    close(vox.unsqueeze(-1), g["smooth_voxels"], TOL, "voxels from `smoothed` (C ABI)")
+    # clamp mask bits == (raw <= 1)
+    bits = mask.cpu().numpy().view(np.uint64)
+    unpacked = np.unpackbits(bits.view(np.uint8), bitorder="little").reshape(B, G, G * G).astype(bool)
+    assert np.array_equal(unpacked, (raw.cpu().numpy().reshape(B, G, G * G) <= 1.0))
+    # transmittance: proj = 1 - T + (e^eps - 1) y0  =>  T <= 1 and consistent with proj where the first voxel is empty
+    assert trans.max().item() <= 1.0 and trans.min().item() >= 0.0
+
+
 def test_point_dropout_matches_reference_rng(R):
     pts = torch.arange(2 * 10 * 3, dtype=torch.float32, device="cuda").reshape(2, 10, 3)
     np.random.seed(7)
