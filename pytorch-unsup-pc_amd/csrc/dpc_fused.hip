@@ -55,7 +55,9 @@ constexpr int kColThreads = 256;
 constexpr int kLocThreads = 256;                     // points per locate block == points per sorted chunk
 constexpr int kL = 16;                               // outputs per thread in the generic in-LDS line convolutions
 constexpr int kLdsLimit = 160 * 1024;                // bytes of LDS a workgroup may use on gfx950
-constexpr int kRedFloats = 1024;  // reduction scratch (13 x 16 floats) + the record table at float offset 512
+constexpr int kRedTab = 256;     // float offset of the record table inside the backward kernel's scratch tail
+constexpr int kRedMask = 400;    // float offset of the staged clamp-mask words
+constexpr int kRedFloats = 1024; // generic kernels: reduction scratch (13 x 16 floats) + record table
 constexpr int kLdsBudget = kLdsLimit - 4096;         // generic slab bytes; the rest holds the reduction scratch
 
 __device__ inline int odd_stride(int w) { return w | 1; }  // generic LDS row stride: odd => conflict-free column walks
@@ -1089,7 +1091,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
         if (zy < nzp * GS) val = *reinterpret_cast<const f32x4*>(src + (size_t)zy * GS + 4 * x4);
         *reinterpret_cast<f32x4*>(slab + zy * Geo::WP + Geo::PAD + 4 * x4) = val;
       }
-      if (cells.nblk <= DPC_WAVE) finish_record_table(rr, reinterpret_cast<int*>(red + 512));
+      if (cells.nblk <= DPC_WAVE) finish_record_table(rr, reinterpret_cast<int*>(red + kRedTab));
       __syncthreads();
       const float w2 = taps_adj.w[0] * taps_adj.w[0];
       for (int i = tid; i < NPL * GS * GS; i += Geo::NT) {
@@ -1102,15 +1104,28 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     } else {
       // adjoint H-pass with its windows read straight from global dT (lanes walk x: coalesced; the halo rows
       // shared by neighbouring segments come from L1/L2), results stored to LDS once
-      uint32_t mbits[wpass_items_per_thread<Geo, GS, NPL>()];
-      wpass_mask_prefetch<Geo, GS, NPL>(mask32, nzp, mbits);  // mask words requested now, consumed after the H-pass
+      // The adjoint W-pass is NOT run over the slab: only ~8 voxels per point are ever gathered (64k per cloud vs
+      // 262k voxels), so it is evaluated at the gathered corners below.  The clamp-mask words of the slab's planes
+      // are staged in LDS (requested now, stored after the H-pass so their latency hides under it).
+      constexpr int MW = NPL * GS * (GS / 32), MPT = (MW + Geo::NT - 1) / Geo::NT;
+      uint32_t mreg[MPT];
+#pragma unroll
+      for (int it = 0; it < MPT; ++it) {
+        const int w = tid + it * Geo::NT;
+        mreg[it] = (w < MW && w / (GS * (GS / 32)) < nzp) ? mask32[w] : 0u;
+      }
       hpass_global<Geo, GS, RB, NPL>(src, nzp, taps_adj, [&](int z, int y, int x, f32x2 val) {
         *reinterpret_cast<f32x2*>(slab + Geo::at(z, y, x)) = val;
       });
-      if (cells.nblk <= DPC_WAVE) finish_record_table(rr, reinterpret_cast<int*>(red + 512));
+      uint32_t* mlds = reinterpret_cast<uint32_t*>(red + kRedMask);
+#pragma unroll
+      for (int it = 0; it < MPT; ++it) {
+        const int w = tid + it * Geo::NT;
+        if (w < MW) mlds[w] = mreg[it];
+      }
+      if (cells.nblk <= DPC_WAVE) finish_record_table(rr, reinterpret_cast<int*>(red + kRedTab));
       __syncthreads();
       DPC_STAMP(9);
-      wpass_fast<Geo, GS, RB, NPL, false, 3>(slab, taps_adj, mbits, nzp);
       DPC_STAMP(10);
     }
   } else {
@@ -1156,15 +1171,43 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     const int i = pt.w;
     const Cell c = cell_from_record(rec);
     float cv[2][2][2];
+    if constexpr (GS > 0 && RB > 0) {
+      // adjoint W-pass evaluated right here, at the two x corners of each of the four (z,y) rows, then masked
+      using Geo = BwdGeo<GS, RB, ZS + 1>;
+      const uint32_t* mlds = reinterpret_cast<const uint32_t*>(red + kRedMask);
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
+      for (int k = 0; k < 2; ++k)
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {
+          cv[k][j][0] = cv[k][j][1] = 0.f;
+          if ((c.iz + k < D) && (c.iy + j < GS)) {
+            const int row = (c.iz - z0 + k) * GS + c.iy + j;
+            const float* rp = slab + row * Geo::WP + Geo::PAD + c.ix - RB;  // x = ix-RB .. ix+1+RB, pads are zero
+            float v[2 * RB + 2];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const bool ok = (c.iz + k < D) && (c.iy + j < H) && (c.ix + e < W);
-          cv[k][j][e] = ok ? corner(c.iz - z0 + k, c.iy + j, c.ix + e) : 0.f;
+            for (int i = 0; i < 2 * RB + 2; ++i) v[i] = rp[i];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              float acc = 0.f;
+#pragma unroll
+              for (int tp = 0; tp < 2 * RB + 1; ++tp) acc = fmaf(taps_adj.w[tp], v[e + tp], acc);
+              const int x = c.ix + e;
+              const bool pass = x < GS && ((mlds[row * (GS / 32) + (x >> 5)] >> (x & 31)) & 1u);
+              cv[k][j][e] = pass ? acc : 0.f;
+            }
+          }
         }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const bool ok = (c.iz + k < D) && (c.iy + j < H) && (c.ix + e < W);
+            cv[k][j][e] = ok ? corner(c.iz - z0 + k, c.iy + j, c.ix + e) : 0.f;
+          }
+    }
     float dgz = 0.f, dgy = 0.f, dgx = 0.f;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -1181,7 +1224,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     dcloud[3 * i + 0] = dpx; dcloud[3 * i + 1] = dpy; dcloud[3 * i + 2] = dpz;
   };
   if (!DPC_ABL(10)) {
-    if (GS > 0 && cells.nblk <= DPC_WAVE) for_each_record_flat(cells, b, reinterpret_cast<const int*>(red + 512), gather);
+    if (GS > 0 && cells.nblk <= DPC_WAVE) for_each_record_flat(cells, b, reinterpret_cast<const int*>(red + kRedTab), gather);
     else for_each_record(cells, b, z0, min(z0 + Zs, D), gather);
   }
   DPC_STAMP(11);
@@ -1377,8 +1420,10 @@ int launch_gather_fast(const DpcParams* p, Cells cells, const float* pc, const f
                        const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask,
                        const float* ds_part, int ntile, float* dpc, float* dsmall, const LossArgs& la, hipStream_t st) {
   using Geo = BwdGeo<GS, RB, ZS + 1>;
-  constexpr size_t lds = (((Geo::slab_floats(ZS + 1) + 3) / 4) * 4 + kRedFloats) * sizeof(float);
+  // slab + scratch tail: reduction floats, record table, staged mask words
+  constexpr size_t lds = (((Geo::slab_floats(ZS + 1) + 3) / 4) * 4 + kRedMask + (ZS + 1) * GS * (GS / 32)) * sizeof(float);
   static_assert(lds <= kLdsLimit, "backward slab does not fit LDS");
+  static_assert(kRedTab >= 13 * (Geo::NT / DPC_WAVE) && kRedMask >= kRedTab + kTabInts, "scratch tail layout");
   auto kern = k_gather_hw<GS, ZS, RB>;
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
