@@ -126,18 +126,25 @@ __device__ inline void finish_record_table(const RecordRange& r, int* tab) {
   if (c == DPC_WAVE - 1) tab[DPC_WAVE] = incl;  // total
 }
 
-template <class F>
-__device__ inline void for_each_record_flat(const Cells& cells, int b, const int* tab, F f) {
-  const int total = tab[DPC_WAVE];
-  for (int j = threadIdx.x; j < total; j += blockDim.x) {
-    int lo = 0, hi = DPC_WAVE;  // largest c with tab[c] <= j (prefix is non-decreasing; empty chunks repeat values)
+// flat index j -> (chunk, sorted position): largest c with tab[c] <= j (prefix non-decreasing; empty chunks repeat)
+__device__ inline void flat_lookup(const int* tab, int j, int& chunk, int& pos) {
+  int lo = 0, hi = DPC_WAVE;
 #pragma unroll
-    for (int step = 0; step < 6; ++step) {
-      const int mid = (lo + hi) >> 1;
-      if (tab[mid] <= j) lo = mid; else hi = mid;
-    }
-    const int pos = tab[DPC_WAVE + 1 + lo] + (j - tab[lo]);
-    f(load_record(cells.recs(b, lo), pos), cells.aux(b, lo) + pos);
+  for (int step = 0; step < 6; ++step) {
+    const int mid = (lo + hi) >> 1;
+    if (tab[mid] <= j) lo = mid; else hi = mid;
+  }
+  chunk = lo;
+  pos = tab[DPC_WAVE + 1 + lo] + (j - tab[lo]);
+}
+
+template <class F>
+__device__ inline void for_each_record_flat(const Cells& cells, int b, const int* tab, F f, int first = 0) {
+  const int total = tab[DPC_WAVE];
+  for (int j = first + threadIdx.x; j < total; j += blockDim.x) {
+    int c, pos;
+    flat_lookup(tab, j, c, pos);
+    f(load_record(cells.recs(b, c), pos), cells.aux(b, c) + pos);
   }
 }
 
@@ -533,10 +540,32 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
     int* tab = reinterpret_cast<int*>(acc + ACC);            // record table sits behind the accumulators
     const bool flat = cells.nblk <= DPC_WAVE;
     DPC_STAMP(0);
+    // Two dependent global reads feed the scatter (chunk offsets, then records); each hides under one half of the
+    // accumulator zero-fill: offsets | zero A | table | barrier | records -> registers | zero B | barrier | atomics.
+    constexpr int PRE = 2;                 // records prefetched per thread (covers 2*NT points per slab)
+    constexpr int ZH = (ACC / 2) / 2;      // float4 words in the first zero-fill half
     RecordRange rr{0, 0};
-    if (flat) rr = load_record_range(cells, b, max(z0 - 1, 0), z0 + nz);  // in flight under the zero-fill
-    for (int i = tid; i < ACC / 2; i += Geo::NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (flat) rr = load_record_range(cells, b, max(z0 - 1, 0), z0 + nz);
+    for (int i = tid; i < ZH; i += Geo::NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (flat) finish_record_table(rr, tab);
+    __syncthreads();
+    PointRec pre[PRE];
+    int npre = 0;
+    if (flat) {
+      const int total = tab[DPC_WAVE];
+#pragma unroll
+      for (int r = 0; r < PRE; ++r) {
+        const int j = tid + r * Geo::NT;
+        pre[r].code = -1; pre[r].tz = pre[r].ty = pre[r].tx = 0.f;
+        if (j < total) {
+          int c, pos;
+          flat_lookup(tab, j, c, pos);
+          pre[r] = load_record(cells.recs(b, c), pos);
+        }
+      }
+      npre = PRE * Geo::NT;
+    }
+    for (int i = ZH + tid; i < ACC / 2; i += Geo::NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     DPC_STAMP(1);
     auto scatter = [&](const PointRec& rec, const int4*) {
@@ -557,8 +586,14 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
         }
       }
     };
-    if (flat) for_each_record_flat(cells, b, tab, scatter);
-    else for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, scatter);
+    if (flat) {
+#pragma unroll
+      for (int r = 0; r < PRE; ++r)
+        if (pre[r].code >= 0) scatter(pre[r], nullptr);
+      for_each_record_flat(cells, b, tab, scatter, npre);  // slabs holding more than PRE*NT points
+    } else {
+      for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, scatter);
+    }
     __syncthreads();
     DPC_STAMP(2);
 
