@@ -53,6 +53,7 @@ def kernel_bytes_per_cloud(n, g):
         "k_splat_hw": 16 * n + 4 * g3 + g3 // 8,        # read records, write T (after W/H passes) + clamp mask
         "k_zcol_fwd": 4 * g3 + 4 * g3 + 4 * g2,         # read T, write smoothed grid, write silhouette
         "k_zcol_bwd": 4 * g3 + 4 * g2 + 4 * g3,         # read smoothed grid + dproj, write dT
+        "k_zcol_fwdbwd": 4 * g3 + 4 * g3 + 8 * g2,      # read T + gt, write dT + silhouette (column backward fused)
         "k_gather_hw": 4 * g3 + g3 // 8 + 16 * n + 24 * n,  # read dT + mask + records + pc, write dpc
     }
 

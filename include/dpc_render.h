@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DPC_ABI_VERSION 6
+#define DPC_ABI_VERSION 7
 #define DPC_MAX_TAPS 63 /* longest 1-D smoothing kernel accepted (pc_gauss_kernel_size) */
 
 enum {
@@ -126,16 +126,24 @@ int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const f
  * and writes loss = sum_s min_k sse / S.  In the backward dproj = 2 (proj - gt) / S * dloss is formed on the fly
  * (never stored) and losing candidates skip all work -- their gradients are exact zeros.
  *   fwd outputs: proj [B,H,W], trans [B,H,W], sse [B], loss [1], winner [B/K] int32 (+ tr_pc|NULL, cells, grid_wh, mask)
- *   bwd inputs : dloss = device scalar arriving at `loss` (NULL = 1) */
+ *   bwd inputs : dloss = device scalar arriving at `loss` (NULL = 1)
+ *
+ * Column half of the backward inside the forward (optional): d loss / d proj is linear in dloss, and the forward's
+ * ray-march kernel holds each ray's column in registers, so with one candidate per sample (K = 1) it can also run the
+ * DRC backward + adjoint D pass for dloss = 1.  Pass bwd_workspace (dpc_workspace_bytes) and bwd_dsmall
+ * (DPC_SMALL_COLS*B floats): when the configuration allows it, *column_backward_done is set to 1, the workspace holds
+ * dT and the ds partials and bwd_dsmall is zeroed; hand the same two buffers and the flag to dpc_project_loss_bwd,
+ * which then launches the gather kernel only (it multiplies by *dloss).  Pass NULLs / 0 to keep the two halves apart. */
 int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                          const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt,
                          int num_candidates, float* tr_pc, void* cells, float* grid_wh, uint64_t* mask, float* proj,
-                         float* trans, float* sse, float* loss, int32_t* winner, void* stream);
+                         float* trans, float* sse, float* loss, int32_t* winner, void* bwd_workspace, float* bwd_dsmall,
+                         int* column_backward_done, void* stream);
 int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                          const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
                          const float* grid_wh, const uint64_t* mask, const float* proj, const float* trans,
-                         const float* gt, int num_candidates, const int32_t* winner, const float* dloss, float* dpc,
-                         float* dsmall, void* workspace, void* stream);
+                         const float* gt, int num_candidates, const int32_t* winner, const float* dloss,
+                         int column_backward_done, float* dpc, float* dsmall, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Stage-level entry points (one per reference function), used for the sub-stage API and to cross-check the

@@ -781,6 +781,7 @@ struct LossArgs {
   float inv_S;
   float* loss_direct;   // forward, K == 1 only: the scalar loss, accumulated by the ray-march blocks (no finalize launch)
   int* winner_out;      // forward, K == 1 only: zero-filled by k_splat_hw
+  int scale_in_gather;  // backward: dT was produced by the forward for dloss = 1; k_gather_hw multiplies by *dloss
 };
 
 __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ sse, int S, int K, float inv_S,
@@ -874,6 +875,96 @@ __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_fwd(Dp
     }
   }
   zcol_fwd_epilogue(P, rc, b, ray, live, trans, y0, proj, trans_out, la);
+}
+
+// Forward 2 + Backward 1 in one launch (fused loss, one pose candidate per sample): the gradient arriving at the
+// silhouette, 2 (proj - gt) / S * dloss, is linear in the scalar dloss, and this kernel already holds the ray's whole
+// column in registers -- so it runs the DRC backward and the adjoint D pass right away for dloss = 1 and writes dT.
+// The backward proper is then k_gather_hw alone, which multiplies by the dloss that actually arrives.  Saves a launch
+// and a second full read of the W/H grid.  Also zeroes the dq/dt/df accumulators and writes the ds partials.
+template <int DD, int RB>
+__global__ __launch_bounds__(kColThreads, 2) void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf,
+                                                             const float* __restrict__ s, TapsT<RB> taps,
+                                                             TapsT<RB> taps_adj, float* __restrict__ proj,
+                                                             float* __restrict__ dT, float* __restrict__ ds_part,
+                                                             float* __restrict__ dsmall, LossArgs la) {
+  const int HW = P.H * P.W;
+  const int b = blockIdx.y, ray = blockIdx.x * kColThreads + threadIdx.x;
+  const bool live = ray < HW;
+  const RayConst rc = ray_const(rh, s, b);
+  float sq = 0.f, ds_acc = 0.f;
+  if (live) {
+    const float* col = Tbuf + (size_t)b * DD * HW + ray;
+    float c[DD], d[DD];
+#pragma unroll
+    for (int z = 0; z < DD; ++z) c[z] = col[(size_t)z * HW];
+    double trans = 1.0;
+    float y0 = 0.f;
+#pragma unroll
+    for (int z = 0; z < DD; ++z) {
+      float v2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 2 * RB + 1; ++k) {
+        const int zz = z + k - RB;
+        if (zz >= 0 && zz < DD) v2 = fmaf(taps.w[k], c[zz], v2);
+      }
+      const float y = drc_clamp(rc, occupancy(rc, v2));
+      if (z == 0) y0 = y;
+      trans *= 1.0 - (double)y;
+      if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    const int yrow = ray / P.W, x = ray - yrow * P.W;
+    const int pix = (P.H - 1 - yrow) * P.W + x;
+    const float pr = (float)(1.0 - trans + (double)rc.em1 * (double)y0);
+    proj[(size_t)b * HW + pix] = pr;
+    const float diff = pr - la.gt[(size_t)b * HW + pix];  // K == 1: sample == cloud
+    sq = diff * diff;
+    const float g = 2.0f * la.inv_S * diff;                // d loss / d proj for dloss = 1
+    const float Tf = (float)trans;
+    float* out = dT + (size_t)b * DD * HW + ray;
+#pragma unroll
+    for (int z = 0; z < DD + RB; ++z) {
+      if (z < DD) {
+        float v2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * RB + 1; ++k) {
+          const int zz = z + k - RB;
+          if (zz >= 0 && zz < DD) v2 = fmaf(taps.w[k], c[zz], v2);
+        }
+        float term;
+        d[z] = drc_voxel_bwd(rc, v2, g, Tf, z == 0, term);
+        ds_acc += term;
+      }
+      if (z >= RB) {
+        const int zo = z - RB;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * RB + 1; ++k) {
+          const int zz = zo + k - RB;
+          if (zz >= 0 && zz < DD) acc = fmaf(taps_adj.w[k], d[zz], acc);
+        }
+        out[(size_t)zo * HW] = acc;
+      }
+      if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // block sums: squared error -> sse[b] and the loss; v2 * dv3 -> this tile's ds partial
+  __shared__ float red[2][kColThreads / DPC_WAVE];
+  sq = wave_sum(sq);
+  ds_acc = wave_sum(ds_acc);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = sq;
+    red[1][threadIdx.x >> 6] = ds_acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tot = 0.f, dst = 0.f;
+    for (int i = 0; i < kColThreads / DPC_WAVE; ++i) { tot += red[0][i]; dst += red[1][i]; }
+    atomicAdd(la.sse + b, tot);
+    atomicAdd(la.loss_direct, tot * la.inv_S);
+    ds_part[(size_t)b * gridDim.x + blockIdx.x] = dst;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)threadIdx.x * gridDim.y + b] = 0.f;  // [col][B]
 }
 
 // Generic depth / tap count: same arithmetic, column re-read from global (L1/L2 serve the re-reads).
@@ -1194,6 +1285,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   // gradient of the out-of-bounds points (bin D)
   if (DPC_ABL(12)) return;
   const Camera cam = load_camera(P, q, t, f, b);
+  const float upstream = (la.scale_in_gather && la.dloss != nullptr) ? *la.dloss : 1.0f;
   CamGrad g;
   camgrad_zero(g);
   float* dcloud = dpc + (size_t)b * N * 3;
@@ -1252,6 +1344,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
         dgy += (cv[a][1][e] - cv[a][0][e]) * c.wz[a] * c.wx[e];
         dgx += (cv[a][e][1] - cv[a][e][0]) * c.wz[a] * c.wy[e];
       }
+    dgz *= upstream; dgy *= upstream; dgx *= upstream;  // 1 unless dT was produced by the forward for dloss = 1
     const float px = __int_as_float(pt.x), py = __int_as_float(pt.y), pz = __int_as_float(pt.z);
     const Projected o = project_point(cam, px, py, pz);
     float dpx, dpy, dpz;
@@ -1291,7 +1384,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     if (blockIdx.x == 0) {
       float ds = 0.f;
       for (int i = 0; i < n_ds_part; ++i) ds += ds_part[(size_t)b * n_ds_part + i];
-      dsmall[(size_t)DPC_COL_DS * P.B + b] = ds;
+      dsmall[(size_t)DPC_COL_DS * P.B + b] = ds * upstream;
     }
   }
   DPC_STAMP(13);
@@ -1549,7 +1642,7 @@ namespace {
 int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, const float* s,
                      const float* host_kern_xy, const float* host_kern_z, float* tr_pc, void* cells, float* raw,
                      float* grid_wh, float* smoothed, uint64_t* mask, float* proj, float* trans, const LossArgs& la,
-                     hipStream_t st) {
+                     void* bwd_workspace, float* bwd_dsmall, hipStream_t st) {
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
   if (!q || !grid_wh || !mask || !proj) return DPC_ERR_NULL;
@@ -1570,6 +1663,23 @@ int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const 
   dim3 gcol(col_tiles(p), p->B);
   const RayHost rh = ray_host(p);
   bool done = false;
+  // fused loss with one candidate per sample and a backward workspace: forward + column backward in one launch
+  if (bwd_workspace != nullptr && bwd_dsmall != nullptr && la.gt != nullptr && la.K == 1 && la.loss_direct != nullptr &&
+      pz.bucket >= 0 && (p->D == 32 || p->D == 64)) {
+    float* dT = static_cast<float*>(bwd_workspace);
+    const size_t grid_bytes = (((size_t)p->B * p->D * p->H * p->W * sizeof(float) + 255) / 256) * 256;
+    float* ds_part = reinterpret_cast<float*>(static_cast<char*>(bwd_workspace) + grid_bytes);
+#define LAUNCH_ZFB(RB)                                                                                             \
+  {                                                                                                                \
+    const TapsT<RB> tzf = make_taps<RB>(host_kern_z, pz, false), tza = make_taps<RB>(host_kern_z, pz, true);       \
+    if (p->D == 32) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, bwd_dsmall, la); \
+    else DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, bwd_dsmall, la); \
+  }
+    DPC_FOR_BUCKET(pz.bucket, LAUNCH_ZFB)
+#undef LAUNCH_ZFB
+    if (rc != DPC_OK) return rc;
+    return launch_ok();
+  }
 #define LAUNCH_ZFWD(RB)                                                                                          \
   {                                                                                                              \
     const TapsT<RB> tz = make_taps<RB>(host_kern_z, pz, false);                                                  \
@@ -1590,10 +1700,11 @@ int project_bwd_impl(const DpcParams* p, const float* pc, const float* q, const 
                      const float* host_kern_xy, const float* host_kern_z, const void* cells, const float* grid_wh,
                      const uint64_t* mask, const float* dproj, const float* proj, const float* trans, const LossArgs& la,
                      float* dpc, float* dsmall, void* workspace, hipStream_t st) {
+  const bool column_done = la.scale_in_gather != 0;  // dT, ds partials and zeroed dsmall come from the forward
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
   if (!q || !grid_wh || !mask || !dsmall || !workspace) return DPC_ERR_NULL;
-  if (la.gt == nullptr ? !dproj : (!proj || !la.winner)) return DPC_ERR_NULL;
+  if (!column_done && (la.gt == nullptr ? !dproj : (!proj || !la.winner))) return DPC_ERR_NULL;
   if (p->N > 0 && p->B > 0 && (!pc || !cells || !dpc)) return DPC_ERR_NULL;
   if ((p->taps_xy > 0 && !host_kern_xy) || (p->taps_z > 0 && !host_kern_z)) return DPC_ERR_NULL;
   if (p->B == 0) return DPC_OK;
@@ -1606,7 +1717,7 @@ int project_bwd_impl(const DpcParams* p, const float* pc, const float* q, const 
   dim3 gcol(ntile, p->B);
   const RayHost rh = ray_host(p);
 
-  bool done = false;
+  bool done = column_done;
 #define LAUNCH_ZBWD(RB)                                                                                           \
   {                                                                                                               \
     const TapsT<RB> tz = make_taps<RB>(host_kern_z, pz, true), tzf = make_taps<RB>(host_kern_z, pz, false);       \
@@ -1614,7 +1725,7 @@ int project_bwd_impl(const DpcParams* p, const float* pc, const float* q, const 
     else if (p->D == 64) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, la); done = true; } \
     else if (p->D == 128) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, la); done = true; } \
   }
-  if (pz.bucket >= 0) { DPC_FOR_BUCKET(pz.bucket, LAUNCH_ZBWD) }
+  if (!done && pz.bucket >= 0) { DPC_FOR_BUCKET(pz.bucket, LAUNCH_ZBWD) }
 #undef LAUNCH_ZBWD
   if (!done) {
     DPC_LAUNCH("k_zcol_bwd", k_zcol_bwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans,
@@ -1631,7 +1742,7 @@ int project_bwd_impl(const DpcParams* p, const float* pc, const float* q, const 
   return rc;
 }
 
-const LossArgs kNoLoss{nullptr, nullptr, nullptr, nullptr, 1, 1.0f, nullptr, nullptr};
+const LossArgs kNoLoss{nullptr, nullptr, nullptr, nullptr, 1, 1.0f, nullptr, nullptr, 0};
 
 }  // namespace
 
@@ -1641,7 +1752,7 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
                     const float* s, const float* host_kern_xy, const float* host_kern_z, float* tr_pc, void* cells,
                     float* raw, float* grid_wh, float* smoothed, uint64_t* mask, float* proj, float* trans, void* stream) {
   return project_fwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, tr_pc, cells, raw, grid_wh, smoothed, mask, proj,
-                          trans, kNoLoss, (hipStream_t)stream);
+                          trans, kNoLoss, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
@@ -1656,15 +1767,21 @@ int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const f
 int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                          const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt,
                          int num_candidates, float* tr_pc, void* cells, float* grid_wh, uint64_t* mask, float* proj,
-                         float* trans, float* sse, float* loss, int32_t* winner, void* stream) {
+                         float* trans, float* sse, float* loss, int32_t* winner, void* bwd_workspace, float* bwd_dsmall,
+                         int* column_backward_done, void* stream) {
   if (!p || !gt || !sse || !loss || !winner) return DPC_ERR_NULL;
   if (num_candidates < 1 || p->B % num_candidates != 0) return DPC_ERR_SHAPE;
   const int S = p->B / num_candidates;
   const bool direct = num_candidates == 1;  // every cloud is its sample's winner: blocks add straight into the loss
   const LossArgs la{gt, sse, nullptr, nullptr, num_candidates, S > 0 ? 1.0f / (float)S : 0.f,
-                    direct ? loss : nullptr, direct ? winner : nullptr};
+                    direct ? loss : nullptr, direct ? winner : nullptr, 0};
+  // the forward can also run the column half of the backward when there is one candidate per sample (see k_zcol_fwdbwd)
+  const TapPlan pz = plan_taps(host_kern_z, p->taps_z);
+  const bool fuse = direct && bwd_workspace && bwd_dsmall && p->B > 0 && pz.bucket >= 0 && (p->D == 32 || p->D == 64);
+  if (column_backward_done) *column_backward_done = fuse ? 1 : 0;
   int rc = project_fwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, tr_pc, cells, nullptr, grid_wh, nullptr, mask,
-                            proj, trans, la, (hipStream_t)stream);
+                            proj, trans, la, fuse ? bwd_workspace : nullptr, fuse ? bwd_dsmall : nullptr,
+                            (hipStream_t)stream);
   if (rc != DPC_OK || p->B == 0 || direct) return rc;
   DPC_LAUNCH("k_loss_finalize", k_loss_finalize, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)sse, S,
              num_candidates, la.inv_S, loss, winner);
@@ -1674,12 +1791,13 @@ int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, co
 int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                          const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
                          const float* grid_wh, const uint64_t* mask, const float* proj, const float* trans,
-                         const float* gt, int num_candidates, const int32_t* winner, const float* dloss, float* dpc,
-                         float* dsmall, void* workspace, void* stream) {
+                         const float* gt, int num_candidates, const int32_t* winner, const float* dloss,
+                         int column_backward_done, float* dpc, float* dsmall, void* workspace, void* stream) {
   if (!p || !gt || !winner || !proj) return DPC_ERR_NULL;
   if (num_candidates < 1 || p->B % num_candidates != 0) return DPC_ERR_SHAPE;
   const int S = p->B / num_candidates;
-  const LossArgs la{gt, nullptr, winner, dloss, num_candidates, S > 0 ? 1.0f / (float)S : 0.f, nullptr, nullptr};
+  const LossArgs la{gt, nullptr, winner, dloss, num_candidates, S > 0 ? 1.0f / (float)S : 0.f, nullptr, nullptr,
+                    column_backward_done ? 1 : 0};
   return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, grid_wh, mask, nullptr, proj, trans, la,
                           dpc, dsmall, workspace, (hipStream_t)stream);
 }

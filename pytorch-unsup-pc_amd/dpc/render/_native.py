@@ -12,7 +12,7 @@ import torch
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "csrc"))
 LIB_PATH = os.path.join(_CSRC, "libdpc_render.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 DPC_MAX_TAPS = 63
 DPC_SMALL_COLS = 12
 COL_DQ, COL_DS, COL_DT, COL_DF = 0, 4, 5, 8
@@ -70,9 +70,9 @@ def lib():
             fn.restype = ctypes.c_int
             fn.argtypes = [pp] + [vp] * nptr
         L.dpc_project_loss_fwd.restype = ctypes.c_int
-        L.dpc_project_loss_fwd.argtypes = [pp] + [vp] * 8 + [ctypes.c_int] + [vp] * 10
+        L.dpc_project_loss_fwd.argtypes = [pp] + [vp] * 8 + [ctypes.c_int] + [vp] * 11 + [ctypes.POINTER(ctypes.c_int), vp]
         L.dpc_project_loss_bwd.restype = ctypes.c_int
-        L.dpc_project_loss_bwd.argtypes = [pp] + [vp] * 13 + [ctypes.c_int] + [vp] * 6
+        L.dpc_project_loss_bwd.argtypes = [pp] + [vp] * 13 + [ctypes.c_int] + [vp] * 2 + [ctypes.c_int] + [vp] * 4
         L.dpc_splat_fwd.restype = ctypes.c_int
         L.dpc_splat_fwd.argtypes = [pp, vp, ctypes.c_int, vp, vp, vp]
         L.dpc_splat_bwd.restype = ctypes.c_int

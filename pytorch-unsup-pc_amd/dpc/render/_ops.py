@@ -179,9 +179,10 @@ class ProjectFused(torch.autograd.Function):
 
 class ProjectLossFused(torch.autograd.Function):
     """pointcloud_project_fast + the caller's silhouette loss (add_proj_loss / proj_loss_pose_candidates) in one
-    autograd node: 4 launches forward (locate, splat, ray march + squared error, finalize), 2 backward.  The
-    silhouette gradient is formed on the fly from proj and gt scaled by the incoming dloss (device scalar);
-    losing pose candidates skip their backward.
+    autograd node.  With one pose candidate per sample and gradients required, the forward's ray-march kernel also runs
+    the column half of the backward (DRC backward + adjoint D pass, for dloss = 1), so the whole step is 3 launches
+    forward + 1 backward; otherwise 3 (+ finalize) forward + 2 backward.  The silhouette gradient is never
+    materialised; losing pose candidates skip their backward.
 
     forward(pc, q, t, f, s, gt [S,H,W,1], geom, K) -> (loss [], proj [B,H,W,1], winner [S] int32)
     """
@@ -207,17 +208,26 @@ class ProjectLossFused(torch.autograd.Function):
         mask = torch.empty((B, geom.D, wpp), dtype=torch.int64, device=dev)
         winner = torch.empty((S,), dtype=torch.int32, device=dev)
         cells = _new_cells(P, dev)
+        # backward buffers handed to the forward so it can run the column half of the backward right away
+        want_grad = any(x is not None and x.requires_grad for x in (pc, q, t, f, s))
+        ws = dsmall = None
+        if want_grad and K == 1:
+            ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
+            dsmall = f32e(N.DPC_SMALL_COLS * B)
+        fused = ctypes.c_int(0)
         kxy, kz = geom.kern_ptrs()
         with torch.cuda.device(dev):
             rc = L.dpc_project_loss_fwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
                                         N.ptr(gt32), K, None, N.ptr(cells), N.ptr(grid_wh), N.ptr(mask), N.ptr(proj),
-                                        N.ptr(trans), N.ptr(sse), N.ptr(loss), N.ptr(winner), N.stream_ptr(dev))
+                                        N.ptr(trans), N.ptr(sse), N.ptr(loss), N.ptr(winner), N.ptr(ws), N.ptr(dsmall),
+                                        ctypes.byref(fused), N.stream_ptr(dev))
         N.check(rc, "dpc_project_loss_fwd")
-        ctx.geom, ctx.K = geom, K
+        ctx.geom, ctx.K, ctx.fused, ctx.fresh = geom, K, bool(fused.value), True
         ctx.inputs = tuple(_meta(x) for x in (pc, q, t, f, s))
         empty = pc32.new_empty(0)
         ctx.save_for_backward(pc32, q32, t32 if t32 is not None else empty, f32 if f32 is not None else empty,
-                              s32 if s32 is not None else empty, gt32, grid_wh, mask, cells, proj, trans, winner)
+                              s32 if s32 is not None else empty, gt32, grid_wh, mask, cells, proj, trans, winner,
+                              ws if ctx.fused else empty, dsmall if ctx.fused else empty)
         ctx.has = (t is not None, f is not None, s is not None)
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(proj, winner)
@@ -227,7 +237,7 @@ class ProjectLossFused(torch.autograd.Function):
     def backward(ctx, dloss, _dproj, _dwinner):
         if dloss is None:
             return (None,) * 8
-        pc32, q32, t32, f32, s32, gt32, grid_wh, mask, cells, proj, trans, winner = ctx.saved_tensors
+        pc32, q32, t32, f32, s32, gt32, grid_wh, mask, cells, proj, trans, winner, ws, dsmall = ctx.saved_tensors
         has_t, has_f, has_s = ctx.has
         t32, f32, s32 = (t32 if has_t else None), (f32 if has_f else None), (s32 if has_s else None)
         geom, dev, L = ctx.geom, pc32.device, N.lib()
@@ -235,20 +245,27 @@ class ProjectLossFused(torch.autograd.Function):
         P = geom.params(B, Npts)
         dl = dloss.detach().to(torch.float32).reshape(())
         dpc = torch.empty_like(pc32)
-        dsmall = torch.empty((N.DPC_SMALL_COLS * B,), dtype=torch.float32, device=dev)
-        ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
+        if ctx.fused:
+            if not ctx.fresh:  # a second backward through the same node: the gather's accumulators must start at zero
+                dsmall[:4 * B].zero_()
+                dsmall[5 * B:9 * B].zero_()
+            ctx.fresh = False
+            out_small = dsmall
+        else:
+            out_small = torch.empty((N.DPC_SMALL_COLS * B,), dtype=torch.float32, device=dev)
+            ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
         kxy, kz = geom.kern_ptrs()
         with torch.cuda.device(dev):
             rc = L.dpc_project_loss_bwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
                                         N.ptr(cells), N.ptr(grid_wh), N.ptr(mask), N.ptr(proj), N.ptr(trans), N.ptr(gt32),
-                                        ctx.K, N.ptr(winner), N.ptr(dl), N.ptr(dpc), N.ptr(dsmall), N.ptr(ws),
-                                        N.stream_ptr(dev))
+                                        ctx.K, N.ptr(winner), N.ptr(dl), int(ctx.fused), N.ptr(dpc), N.ptr(out_small),
+                                        N.ptr(ws), N.stream_ptr(dev))
         N.check(rc, "dpc_project_loss_bwd")
         pc, q, t, f, s = ctx.inputs
-        return (_like_input(dpc, pc), _like_input(_small(dsmall, N.COL_DQ, 4, B), q),
-                _like_input(_small(dsmall, N.COL_DT, 3, B), t) if has_t else None,
-                _like_input(_small(dsmall, N.COL_DF, 1, B), f) if has_f else None,
-                _like_input(_small(dsmall, N.COL_DS, 1, B), s) if has_s else None, None, None, None)
+        return (_like_input(dpc, pc), _like_input(_small(out_small, N.COL_DQ, 4, B), q),
+                _like_input(_small(out_small, N.COL_DT, 3, B), t) if has_t else None,
+                _like_input(_small(out_small, N.COL_DF, 1, B), f) if has_f else None,
+                _like_input(_small(out_small, N.COL_DS, 1, B), s) if has_s else None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------------

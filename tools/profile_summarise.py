@@ -54,7 +54,7 @@ for k in ("calib_copy_dword", "calib_copy_dwordx4"):
 
 fetch, write = counter_avg("fetch", "FETCH_SIZE"), counter_avg("write", "WRITE_SIZE")
 # which calibration applies: column kernels and locate use dword-per-lane streams, slab kernels 16 B per lane
-width = {"k_zcol_fwd": "calib_copy_dword", "k_zcol_bwd": "calib_copy_dword", "k_locate": "calib_copy_dword",
+width = {"k_zcol_fwd": "calib_copy_dword", "k_zcol_bwd": "calib_copy_dword", "k_zcol_fwdbwd": "calib_copy_dword", "k_locate": "calib_copy_dword",
          "k_splat_hw": "calib_copy_dwordx4", "k_gather_hw": "calib_copy_dwordx4", "k_loss_finalize": "calib_copy_dword"}
 kern = {}
 for k in sorted(set(fetch) | set(write)):
