@@ -52,6 +52,12 @@ namespace {
 
 constexpr int kSlabThreads = 1024;
 constexpr int kColThreads = 256;
+// k_zcol_fwdbwd's per-cloud word: [63:51] blocks arrived, [50:0] squared error, 30 fractional bits (a cloud's sum is
+// at most H*W <= 2^20)
+constexpr int kSseCountShift = 51, kSseFrac = 30;
+#ifndef DPC_ZFB_RPL
+#define DPC_ZFB_RPL 1  // rays per lane in k_zcol_fwdbwd (1 or 2)
+#endif
 constexpr int kLocThreads = 256;                     // points per locate block == points per sorted chunk
 constexpr int kL = 16;                               // outputs per thread in the generic in-LDS line convolutions
 constexpr int kLdsLimit = 160 * 1024;                // bytes of LDS a workgroup may use on gfx950
@@ -511,11 +517,13 @@ template <int GS, int ZS, int RB>
 __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells cells, TapsT<RB> taps, int zs_rt,
                                                            float* __restrict__ raw, float* __restrict__ Tbuf,
                                                            uint64_t* __restrict__ mask, float* __restrict__ sse,
-                                                           float* __restrict__ loss_zero, int* __restrict__ winner_zero) {
+                                                           float* __restrict__ loss_zero, int* __restrict__ winner_zero,
+                                                           unsigned long long* __restrict__ ticket_zero) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
   if (sse != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {  // k_zcol_fwd accumulates into these
     sse[blockIdx.y] = 0.f;
     if (winner_zero != nullptr) winner_zero[blockIdx.y] = 0;   // K == 1: sample == cloud, candidate 0 wins
+    if (ticket_zero != nullptr) ticket_zero[blockIdx.y] = 0ull;  // k_zcol_fwdbwd's per-cloud sum-and-count word
     if (loss_zero != nullptr && blockIdx.y == 0) *loss_zero = 0.f;
   }
   const int D = P.D, H = P.H, W = P.W;
@@ -882,87 +890,161 @@ __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_fwd(Dp
 // column in registers -- so it runs the DRC backward and the adjoint D pass right away for dloss = 1 and writes dT.
 // The backward proper is then k_gather_hw alone, which multiplies by the dloss that actually arrives.  Saves a launch
 // and a second full read of the W/H grid.  Also zeroes the dq/dt/df accumulators and writes the ds partials.
-template <int DD, int RB>
-__global__ __launch_bounds__(kColThreads, 2) void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf,
-                                                             const float* __restrict__ s, TapsT<RB> taps,
-                                                             TapsT<RB> taps_adj, float* __restrict__ proj,
-                                                             float* __restrict__ dT, float* __restrict__ ds_part,
-                                                             float* __restrict__ dsmall, LossArgs la) {
+//
+// Written one ray per lane with a forward pass, a recomputed D pass and a branch-free but long DRC backward, this
+// kernel was VALU-bound (measured: 6 us of loads, 12 us of arithmetic), so the arithmetic is cut to the bone instead:
+// per voxel the forward leaves a single value behind, the clamped occupancy y, with "the clamps acted" (no gradient)
+// encoded as y = -inf: then 1 - y = +inf, rcp gives 0, and the backward needs no compare/select and no second D pass.
+//   y = med3(s v2, eps, 1-eps)  [= the reference's clamp(clamp(s v2, 0, 1), eps, 1-eps)],  inside <=> y == s v2
+//   dL/dv3 = g T / (1 - y) (+ g (e^eps - 1) for the first voxel),  dL/ds = sum y dL/dv3 / s  (inside: v2 = y / s)
+// RPL = rays per lane: neighbouring rays x .. x+RPL-1 (RPL divides W, so they share an image row).
+template <int DD, int RB, int RPL>
+__global__ __launch_bounds__(kColThreads, (RPL * DD <= 64 ? 2 : 1))
+void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, const float* __restrict__ s, TapsT<RB> taps,
+                   TapsT<RB> taps_adj, float* __restrict__ proj, float* __restrict__ dT, float* __restrict__ ds_part,
+                   int n_ds_part, unsigned long long* __restrict__ tickets, float* __restrict__ dsmall, LossArgs la) {
+  typedef float vec __attribute__((ext_vector_type(RPL)));
   const int HW = P.H * P.W;
-  const int b = blockIdx.y, ray = blockIdx.x * kColThreads + threadIdx.x;
+  const int b = blockIdx.y, ray = RPL * (blockIdx.x * kColThreads + threadIdx.x);
   const bool live = ray < HW;
   const RayConst rc = ray_const(rh, s, b);
   float sq = 0.f, ds_acc = 0.f;
+  float y[DD][RPL], g[RPL], gT[RPL];
   if (live) {
     const float* col = Tbuf + (size_t)b * DD * HW + ray;
-    float c[DD], d[DD];
-#pragma unroll
-    for (int z = 0; z < DD; ++z) c[z] = col[(size_t)z * HW];
-    double trans = 1.0;
-    float y0 = 0.f;
+    float c[DD][RPL];  // T column, then y (encoded), then dL/dv3: each value dies as the next is born
 #pragma unroll
     for (int z = 0; z < DD; ++z) {
-      float v2 = 0.f;
+      const vec v = *reinterpret_cast<const vec*>(col + (size_t)z * HW);
 #pragma unroll
-      for (int k = 0; k < 2 * RB + 1; ++k) {
-        const int zz = z + k - RB;
-        if (zz >= 0 && zz < DD) v2 = fmaf(taps.w[k], c[zz], v2);
-      }
-      const float y = drc_clamp(rc, occupancy(rc, v2));
-      if (z == 0) y0 = y;
-      trans *= 1.0 - (double)y;
-      if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      for (int r = 0; r < RPL; ++r) c[z][r] = v[r];
     }
-    const int yrow = ray / P.W, x = ray - yrow * P.W;
-    const int pix = (P.H - 1 - yrow) * P.W + x;
-    const float pr = (float)(1.0 - trans + (double)rc.em1 * (double)y0);
-    proj[(size_t)b * HW + pix] = pr;
-    const float diff = pr - la.gt[(size_t)b * HW + pix];  // K == 1: sample == cloud
-    sq = diff * diff;
-    const float g = 2.0f * la.inv_S * diff;                // d loss / d proj for dloss = 1
-    const float Tf = (float)trans;
-    float* out = dT + (size_t)b * DD * HW + ray;
+    if (DPC_ABL(16)) {  // diagnostic: loads only
+      float sum = 0.f;
 #pragma unroll
-    for (int z = 0; z < DD + RB; ++z) {
-      if (z < DD) {
+      for (int z = 0; z < DD; ++z)
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) sum += c[z][r];
+      if (sum == 123.456f) proj[0] = sum;
+      return;
+    }
+    const float ninf = -__builtin_inff();
+    double tr[RPL];
+    float yfirst[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) tr[r] = 1.0;
+#pragma unroll
+    for (int z = 0; z < DD; ++z) {
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) {
         float v2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 2 * RB + 1; ++k) {
           const int zz = z + k - RB;
-          if (zz >= 0 && zz < DD) v2 = fmaf(taps.w[k], c[zz], v2);
+          if (zz >= 0 && zz < DD) v2 = fmaf(taps.w[k], c[zz][r], v2);
         }
-        float term;
-        d[z] = drc_voxel_bwd(rc, v2, g, Tf, z == 0, term);
-        ds_acc += term;
-      }
-      if (z >= RB) {
-        const int zo = z - RB;
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < 2 * RB + 1; ++k) {
-          const int zz = zo + k - RB;
-          if (zz >= 0 && zz < DD) acc = fmaf(taps_adj.w[k], d[zz], acc);
-        }
-        out[(size_t)zo * HW] = acc;
+        const float x = v2 * rc.s;  // s = 1 when there is no scale input
+        const float yc = __builtin_amdgcn_fmed3f(x, rc.eps, rc.hi);
+        tr[r] = fma(-(double)yc, tr[r], tr[r]);  // T *= 1 - y, one rounding
+        y[z][r] = (yc == x) ? yc : ninf;
+        if (z == 0) yfirst[r] = yc;
       }
       if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
+    // silhouettes (row flip folded into the index), squared error, d loss / d proj for dloss = 1
+    const int yrow = ray / P.W, xcol = ray - yrow * P.W;
+    const int pix = (P.H - 1 - yrow) * P.W + xcol;
+    vec pr;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) pr[r] = (float)(1.0 - tr[r] + (double)rc.em1 * (double)yfirst[r]);
+    *reinterpret_cast<vec*>(proj + (size_t)b * HW + pix) = pr;
+    if (DPC_ABL(17)) return;  // diagnostic: forward only
+    const vec gtv = *reinterpret_cast<const vec*>(la.gt + (size_t)b * HW + pix);  // K == 1: sample == cloud
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) {
+      const float diff = pr[r] - gtv[r];
+      sq = fmaf(diff, diff, sq);
+      g[r] = 2.0f * la.inv_S * diff;
+      gT[r] = g[r] * (float)tr[r];
+    }
   }
-  // block sums: squared error -> sse[b] and the loss; v2 * dv3 -> this tile's ds partial
+  // Squared error of the cloud and the loss.  Float atomics from every block onto sse[b] and the one loss word cost
+  // 3.4 us here (device-scope atomics execute memory-side, ~7 ns apiece on one address, and the issuing wave's stores
+  // queue behind them), and a release/acquire hand-over between blocks costs an L2 write-back per block (the eight
+  // XCD L2s are not coherent with each other).  So each block makes ONE relaxed 64-bit atomic add to its cloud's word:
+  // the squared error in fixed point (kSseFrac fractional bits) plus a block count in the top bits.  The returned value
+  // is looked at only after the backward half; whoever drew the last ticket holds the cloud's complete sum -- exact
+  // integer adds, so sse[b] does not depend on the order the blocks arrived in -- and makes the cloud's single add
+  // to the loss.
   __shared__ float red[2][kColThreads / DPC_WAVE];
   sq = wave_sum(sq);
-  ds_acc = wave_sum(ds_acc);
-  if ((threadIdx.x & 63) == 0) {
-    red[0][threadIdx.x >> 6] = sq;
-    red[1][threadIdx.x >> 6] = ds_acc;
+  if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = sq;
+  __syncthreads();
+  unsigned long long mine = 0ull, before = 0ull;
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int i = 0; i < kColThreads / DPC_WAVE; ++i) tot += red[0][i];
+    mine = (1ull << kSseCountShift) | (unsigned long long)((double)tot * (double)(1ull << kSseFrac) + 0.5);
+    before = __hip_atomic_fetch_add(tickets + b, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (live) {
+    float dsv[RPL];
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) dsv[r] = 0.f;
+    float wadj[2 * RB + 1];  // adjoint taps with the occupancy scale folded in: dT = s * adj(dL/dv3)
+#pragma unroll
+    for (int k = 0; k < 2 * RB + 1; ++k) wadj[k] = taps_adj.w[k] * rc.s;
+    float* out = dT + (size_t)b * DD * HW + ray;
+#pragma unroll
+    for (int z = 0; z < DD + RB; ++z) {
+      if (z < DD) {
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          const float yv = y[z][r];
+          float e = gT[r] * __builtin_amdgcn_rcpf(1.0f - yv);  // 1 - (-inf) = +inf -> 0
+          if (z == 0) e += yv > 0.f ? g[r] * rc.em1 : 0.f;
+          dsv[r] = fmaf(__builtin_amdgcn_fmed3f(yv, 0.f, 1.f), e, dsv[r]);  // -inf -> 0
+          y[z][r] = e;  // y[z] is dead from here on: its register carries dL/dv3 for the adjoint window
+        }
+      }
+      if (z >= RB) {
+        const int zo = z - RB;
+        vec acc;
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) {
+          float a = 0.f;
+#pragma unroll
+          for (int k = 0; k < 2 * RB + 1; ++k) {
+            const int zz = zo + k - RB;
+            if (zz >= 0 && zz < DD) a = fmaf(wadj[k], y[zz][r], a);
+          }
+          acc[r] = a;
+        }
+        if (!DPC_ABL(18) || acc[0] == 123.456f) *reinterpret_cast<vec*>(out + (size_t)zo * HW) = acc;
+      }
+      if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    float dsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < RPL; ++r) dsum += dsv[r];
+    ds_acc = (rc.has_s && rc.s != 0.f) ? dsum / rc.s : 0.f;
+  }
+  if (DPC_ABL(19)) { if (ds_acc == 123.456f) proj[1] = sq; return; }
+  // v2 * dL/dv3 -> this tile's ds partial
+  ds_acc = wave_sum(ds_acc);
+  if ((threadIdx.x & 63) == 0) red[1][threadIdx.x >> 6] = ds_acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    float tot = 0.f, dst = 0.f;
-    for (int i = 0; i < kColThreads / DPC_WAVE; ++i) { tot += red[0][i]; dst += red[1][i]; }
-    atomicAdd(la.sse + b, tot);
-    atomicAdd(la.loss_direct, tot * la.inv_S);
-    ds_part[(size_t)b * gridDim.x + blockIdx.x] = dst;
+    float dst = 0.f;
+    for (int i = 0; i < kColThreads / DPC_WAVE; ++i) dst += red[1][i];
+    // k_gather_hw sums n_ds_part partials per cloud (one per kColThreads rays); with RPL > 1 this grid has fewer blocks
+    for (int i = blockIdx.x; i < n_ds_part; i += gridDim.x) ds_part[(size_t)b * n_ds_part + i] = i == (int)blockIdx.x ? dst : 0.f;
+    if ((before >> kSseCountShift) == gridDim.x - 1) {  // every other block of this cloud has added its share
+      const unsigned long long sum = (before + mine) & ((1ull << kSseCountShift) - 1);
+      const float tot = (float)((double)sum * (1.0 / (double)(1ull << kSseFrac)));
+      la.sse[b] = tot;
+      atomicAdd(la.loss_direct, tot * la.inv_S);
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)threadIdx.x * gridDim.y + b] = 0.f;  // [col][B]
 }
@@ -1506,7 +1588,7 @@ constexpr int kBwdZs64 = DPC_BWD_ZS64;  // cell layers per backward slab at G = 
 // ---- slab kernel dispatch: specialised when H = W in {32, 64, 128} and the padded slab fits, else generic
 template <int GS, int ZS, int RB>
 int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
-                      uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, hipStream_t st) {
+                      uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st) {
   using Geo = FwdGeo<GS, ZS, RB>;
   constexpr size_t lds = ((size_t)ZS * GS * (GS + Geo::PAD) + Geo::PAD) * sizeof(unsigned long long) + kTabInts * sizeof(int);
   static_assert(lds >= Geo::slab_floats(ZS) * sizeof(float), "the fp32 slab reuses the accumulator memory");
@@ -1515,20 +1597,20 @@ int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const T
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_splat_hw", kern, dim3((p->D + ZS - 1) / ZS, p->B), dim3(Geo::NT), lds, st, *p, cells,
-             make_taps<RB>(kxy, pxy, false), ZS, raw, Tbuf, mask, sse, loss_zero, winner_zero);
+             make_taps<RB>(kxy, pxy, false), ZS, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
   return launch_ok();
 }
 
 template <int RB>
 int launch_splat(const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
-                 uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, hipStream_t st) {
+                 uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st) {
   if (p->H == p->W) {
     if constexpr (RB <= 4) {
-      if (p->H == 32) return launch_splat_fast<32, 4, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, st);
-      if (p->H == 128) return launch_splat_fast<128, 1, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, st);
+      if (p->H == 32) return launch_splat_fast<32, 4, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
+      if (p->H == 128) return launch_splat_fast<128, 1, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
     }
     if constexpr (RB <= 10) {
-      if (p->H == 64) return launch_splat_fast<64, kFwdZs64, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, st);
+      if (p->H == 64) return launch_splat_fast<64, kFwdZs64, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
     }
   }
   const int fit = planes_fit(p);
@@ -1539,7 +1621,7 @@ int launch_splat(const DpcParams* p, Cells cells, const float* kxy, const TapPla
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_splat_hw", kern, dim3((p->D + Zs - 1) / Zs, p->B), dim3(slab_threads(p)), lds, st, *p, cells,
-             make_taps<RB>(kxy, pxy, false), Zs, raw, Tbuf, mask, sse, loss_zero, winner_zero);
+             make_taps<RB>(kxy, pxy, false), Zs, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
   return launch_ok();
 }
 
@@ -1610,7 +1692,7 @@ size_t dpc_cells_bytes(const DpcParams* p) {
 size_t dpc_workspace_bytes(const DpcParams* p) {
   if (validate(p) != DPC_OK) return 0;
   const size_t grid = (size_t)p->B * p->D * p->H * p->W * sizeof(float);
-  const size_t parts = (size_t)p->B * col_tiles(p) * sizeof(float);
+  const size_t parts = (size_t)p->B * col_tiles(p) * sizeof(float) + (size_t)p->B * 8 + 8;  // ds partials, sum-and-count words
   return ((grid + 255) / 256) * 256 + ((parts + 255) / 256) * 256;
 }
 
@@ -1632,12 +1714,21 @@ int dpc_splat_fwd(const DpcParams* p, const void* tr, int tr_is_f64, void* cells
   hipStream_t st = (hipStream_t)stream;
   if ((rc = launch_locate(p, tr_is_f64 ? 2 : 1, tr, nullptr, nullptr, nullptr, nullptr, cells, st)) != DPC_OK) return rc;
   const TapPlan none{0, 0, 0};
-  return launch_splat<0>(p, cells_view(p, cells), nullptr, none, vox, nullptr, nullptr, nullptr, nullptr, nullptr, st);
+  return launch_splat<0>(p, cells_view(p, cells), nullptr, none, vox, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, st);
 }
 
 }  // extern "C"
 
 namespace {
+
+// k_zcol_fwdbwd handles one pose candidate per sample, 32- or 64-deep columns with a bucketed z kernel; with two rays
+// per lane its accesses are float2: an even image width and 8-byte aligned grids/images.
+bool can_fuse_column_backward(const DpcParams* p, const TapPlan& pz, int K, const void* grid_wh, const void* proj,
+                              const void* gt, const void* workspace) {
+  const auto aligned8 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 7u) == 0; };
+  return K == 1 && gt != nullptr && p->B > 0 && pz.bucket >= 0 && (p->D == 32 || p->D == 64) && p->W % DPC_ZFB_RPL == 0 &&
+         aligned8(grid_wh) && aligned8(proj) && aligned8(gt) && aligned8(workspace);
+}
 
 int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, const float* s,
                      const float* host_kern_xy, const float* host_kern_z, float* tr_pc, void* cells, float* raw,
@@ -1655,7 +1746,14 @@ int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const 
 
   if ((rc = launch_locate(p, 0, pc, q, t, f, tr_pc, cells, st)) != DPC_OK) return rc;
   const Cells cv = cells_view(p, cells);
-#define LAUNCH_SPLAT(RB) rc = launch_splat<RB>(p, cv, host_kern_xy, pxy, raw, Tbuf, mask, la.sse, la.loss_direct, la.winner_out, st)
+  // fused loss with one candidate per sample and a backward workspace: the ray-march kernel also runs the column
+  // backward; its per-cloud sum-and-count words live behind the ds partials and are zeroed by the slab kernel
+  const bool fuse_bwd = bwd_workspace != nullptr && bwd_dsmall != nullptr && la.loss_direct != nullptr &&
+                        can_fuse_column_backward(p, pz, la.K, Tbuf, proj, la.gt, bwd_workspace);
+  const size_t grid_bytes = (((size_t)p->B * p->D * p->H * p->W * sizeof(float) + 255) / 256) * 256;
+  float* ds_part = fuse_bwd ? reinterpret_cast<float*>(static_cast<char*>(bwd_workspace) + grid_bytes) : nullptr;
+  unsigned long long* tickets = fuse_bwd ? reinterpret_cast<unsigned long long*>(ds_part + (size_t)p->B * col_tiles(p)) : nullptr;
+#define LAUNCH_SPLAT(RB) rc = launch_splat<RB>(p, cv, host_kern_xy, pxy, raw, Tbuf, mask, la.sse, la.loss_direct, la.winner_out, tickets, st)
   DPC_FOR_BUCKET(pxy.bucket, LAUNCH_SPLAT)
 #undef LAUNCH_SPLAT
   if (rc != DPC_OK) return rc;
@@ -1663,17 +1761,16 @@ int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const 
   dim3 gcol(col_tiles(p), p->B);
   const RayHost rh = ray_host(p);
   bool done = false;
-  // fused loss with one candidate per sample and a backward workspace: forward + column backward in one launch
-  if (bwd_workspace != nullptr && bwd_dsmall != nullptr && la.gt != nullptr && la.K == 1 && la.loss_direct != nullptr &&
-      pz.bucket >= 0 && (p->D == 32 || p->D == 64)) {
+  if (fuse_bwd) {
     float* dT = static_cast<float*>(bwd_workspace);
-    const size_t grid_bytes = (((size_t)p->B * p->D * p->H * p->W * sizeof(float) + 255) / 256) * 256;
-    float* ds_part = reinterpret_cast<float*>(static_cast<char*>(bwd_workspace) + grid_bytes);
+    const int ntile = col_tiles(p);
+    constexpr int kRpl = DPC_ZFB_RPL;
+    dim3 gpair((p->H * p->W / kRpl + kColThreads - 1) / kColThreads, p->B);
 #define LAUNCH_ZFB(RB)                                                                                             \
   {                                                                                                                \
     const TapsT<RB> tzf = make_taps<RB>(host_kern_z, pz, false), tza = make_taps<RB>(host_kern_z, pz, true);       \
-    if (p->D == 32) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, bwd_dsmall, la); \
-    else DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, bwd_dsmall, la); \
+    if (p->D == 32) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<32, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, bwd_dsmall, la); \
+    else DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<64, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, bwd_dsmall, la); \
   }
     DPC_FOR_BUCKET(pz.bucket, LAUNCH_ZFB)
 #undef LAUNCH_ZFB
@@ -1777,7 +1874,8 @@ int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, co
                     direct ? loss : nullptr, direct ? winner : nullptr, 0};
   // the forward can also run the column half of the backward when there is one candidate per sample (see k_zcol_fwdbwd)
   const TapPlan pz = plan_taps(host_kern_z, p->taps_z);
-  const bool fuse = direct && bwd_workspace && bwd_dsmall && p->B > 0 && pz.bucket >= 0 && (p->D == 32 || p->D == 64);
+  const bool fuse = direct && bwd_workspace && bwd_dsmall &&
+                    can_fuse_column_backward(p, pz, num_candidates, grid_wh, proj, gt, bwd_workspace);
   if (column_backward_done) *column_backward_done = fuse ? 1 : 0;
   int rc = project_fwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, tr_pc, cells, nullptr, grid_wh, nullptr, mask,
                             proj, trans, la, fuse ? bwd_workspace : nullptr, fuse ? bwd_dsmall : nullptr,
