@@ -34,11 +34,28 @@ struct Camera {
   float f, d;
 };
 
-__device__ inline Camera load_camera(const DpcParams& P, const float* __restrict__ q, const float* __restrict__ t,
-                                     const float* __restrict__ f, int b) {
+// The camera inputs as they sit in memory: loaded early (a dependent global read), turned into a Camera where needed.
+struct CameraRaw {
+  float q[4], t[3], f;
+};
+
+__device__ inline CameraRaw load_camera_raw(const DpcParams& P, const float* __restrict__ q, const float* __restrict__ t,
+                                            const float* __restrict__ f, int b) {
+  CameraRaw r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.q[i] = q[4 * b + i];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) r.t[i] = t ? t[3 * b + i] : 0.f;
+  r.f = f ? f[b] : P.focal_length;
+  return r;
+}
+
+// Backward-side camera (the forward uses the reference-exact CameraRef below).
+__device__ inline Camera make_camera(const DpcParams& P, const CameraRaw& raw) {
   Camera c;
   // normalise in double once per thread: keeps R orthogonal to ~1e-16 before the single rounding to fp32
-  double w = q[4 * b + 0], x = q[4 * b + 1], y = q[4 * b + 2], z = q[4 * b + 3];
+  // (an all-fp32 variant measured no faster and cost a third of the d(q) parity margin)
+  double w = raw.q[0], x = raw.q[1], y = raw.q[2], z = raw.q[3];
   double n = sqrt(w * w + x * x + y * y + z * z);
   double in = 1.0 / n;
   w *= in; x *= in; y *= in; z *= in;
@@ -53,12 +70,15 @@ __device__ inline Camera load_camera(const DpcParams& P, const float* __restrict
   c.r[6] = (float)(2.0 * (x * z - w * y));
   c.r[7] = (float)(2.0 * (y * z + w * x));
   c.r[8] = (float)(1.0 - 2.0 * (x * x + y * y));
-  c.tx = t ? t[3 * b + 0] : 0.f;
-  c.ty = t ? t[3 * b + 1] : 0.f;
-  c.tz = t ? t[3 * b + 2] : 0.f;
-  c.f = f ? f[b] : P.focal_length;
+  c.tx = raw.t[0]; c.ty = raw.t[1]; c.tz = raw.t[2];
+  c.f = raw.f;
   c.d = P.camera_distance;
   return c;
+}
+
+__device__ inline Camera load_camera(const DpcParams& P, const float* __restrict__ q, const float* __restrict__ t,
+                                     const float* __restrict__ f, int b) {
+  return make_camera(P, load_camera_raw(P, q, t, f, b));
 }
 
 struct Projected {

@@ -1274,6 +1274,9 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   }
   const int nzp = min(Zs + 1, D - z0);  // planes present (cell layers + halo)
   const int tid = threadIdx.x, nthr = blockDim.x;
+  // camera inputs and the upstream scalar: requested now, first used after the slab is in LDS
+  const CameraRaw cam_raw = load_camera_raw(P, q, t, f, b);
+  const float upstream = (la.scale_in_gather && la.dloss != nullptr) ? *la.dloss : 1.0f;
   const int wpp = (HW + 63) / 64;
   const float* src = dT + ((size_t)b * D + z0) * HW;
   const uint64_t* mrow = mask + ((size_t)b * D + z0) * wpp;
@@ -1366,8 +1369,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   // gather: every in-bounds point belongs to the slab of its cell layer iz; slab 0 also zero-fills the
   // gradient of the out-of-bounds points (bin D)
   if (DPC_ABL(12)) return;
-  const Camera cam = load_camera(P, q, t, f, b);
-  const float upstream = (la.scale_in_gather && la.dloss != nullptr) ? *la.dloss : 1.0f;
+  const Camera cam = make_camera(P, cam_raw);
   CamGrad g;
   camgrad_zero(g);
   float* dcloud = dpc + (size_t)b * N * 3;
