@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DPC_ABI_VERSION 7
+#define DPC_ABI_VERSION 8
 #define DPC_MAX_TAPS 63 /* longest 1-D smoothing kernel accepted (pc_gauss_kernel_size) */
 
 enum {
@@ -186,6 +186,17 @@ int dpc_drc_bwd(const DpcParams* p, const float* vox, const float* dproj, const 
  * winner [S], dpred [S*K, n_pix] = d loss / d pred (zero for losing candidates). */
 int dpc_silhouette_loss(const float* gt, const float* pred, int S, int K, int n_pix, float* loss_part, int32_t* winner,
                         float* dpred, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Evaluation side: point_cloud_distance (dpc/util/point_cloud_distance.py:25-40), the kernel of
+ * the Chamfer evaluation (dpc/run/eval_chamfer_to.py:24-44).  For every source point vs[i] ([ns,3]) the nearest target
+ * vt[j] ([nt,3]): idx[i] = first j minimising dist = sqrt(sum((vt[j]-vs[i])^2)) (int64, like torch.argmin),
+ * min_dist[i] that distance, proj[i] = vt[idx[i]].  fp32, or fp64 when is_f64 (the evaluation runs in fp64); proj,
+ * min_dist, idx may each be NULL.  workspace: dpc_nearest_workspace_bytes(ns, nt, is_f64) bytes of scratch.
+ * ------------------------------------------------------------------------------------------------- */
+size_t dpc_nearest_workspace_bytes(int ns, int nt, int is_f64);
+int dpc_point_cloud_distance(const void* vs, const void* vt, int ns, int nt, int is_f64, void* proj, void* min_dist,
+                             int64_t* idx, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Opt-in measurement aid (nothing in the reference corresponds to it).  After dpc_profile_enable(capacity)

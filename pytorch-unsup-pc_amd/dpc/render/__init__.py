@@ -25,6 +25,7 @@ __all__ = [
     "drc_projection", "drc_event_probabilities", "drc_depth_projection", "drc_depth_grid", "pc_point_dropout",
     "quaternion_rotate", "quaternion_multiply", "quaternion_conjugate", "quaternion_normalise",
     "get_smooth_sigma", "get_dropout_prob", "ProjectionOutputs", "silhouette_loss", "pointcloud_project_loss",
+    "point_cloud_distance", "compute_distance", "chamfer_distances",
 ]
 
 
@@ -374,3 +375,52 @@ def get_dropout_prob(cfg, global_step):
     slope = (1.0 - k0) / (cfg.pc_point_dropout_end_step - cfg.pc_point_dropout_start_step)
     keep = slope * (global_step / cfg.max_number_of_steps) + (k0 - slope * cfg.pc_point_dropout_start_step)
     return max(min(keep, 1.0), k0)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Evaluation side: nearest target point / Chamfer      reference: dpc/util/point_cloud_distance.py:25-40,
+#                                           dpc/run/eval_chamfer_to.py:24-44, 119-123
+# ------------------------------------------------------------------------------------------------------
+def point_cloud_distance(Vs, Vt):
+    """For each point of Vs [Ns,3] the closest point of Vt [Nt,3] (point_cloud_distance.py:25-40).
+
+    Returns (proj [Ns,3] = Vt[idx], minDist [Ns], idx [Ns] int64) like the reference; fp32 or fp64 after the inputs.
+    Nothing of size Ns x Nt is materialised.  No gradient (the reference only evaluates with it)."""
+    dev = _native.require_device(Vs, Vt)
+    if Vs.dim() != 2 or Vt.dim() != 2 or Vs.shape[1] != 3 or Vt.shape[1] != 3:
+        raise ValueError("point_cloud_distance expects [Ns,3] and [Nt,3], got %s and %s" % (tuple(Vs.shape), tuple(Vt.shape)))
+    dtype = torch.float64 if torch.float64 in (Vs.dtype, Vt.dtype) else torch.float32
+    vs, vt = Vs.detach().to(dtype).contiguous(), Vt.detach().to(dtype).contiguous()
+    ns, nt = vs.shape[0], vt.shape[0]
+    if nt == 0 and ns > 0:
+        raise IndexError("point_cloud_distance: empty target cloud (argmin of an empty sequence)")
+    L = _native.lib()
+    is64 = int(dtype == torch.float64)
+    proj = torch.empty((ns, 3), dtype=dtype, device=dev)
+    dist = torch.empty((ns,), dtype=dtype, device=dev)
+    idx = torch.empty((ns,), dtype=torch.int64, device=dev)
+    ws = torch.empty((max(L.dpc_nearest_workspace_bytes(ns, nt, is64), 16),), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        rc = L.dpc_point_cloud_distance(_native.ptr(vs), _native.ptr(vt), ns, nt, is64, _native.ptr(proj), _native.ptr(dist),
+                                        _native.ptr(idx), _native.ptr(ws), _native.stream_ptr(dev))
+    _native.check(rc, "dpc_point_cloud_distance")
+    return proj, dist, idx
+
+
+def compute_distance(cfg, source_np, target_np, device=None):
+    """eval_chamfer_to.py:24-44: numpy in, (min_dist, idx) numpy out (both float64 arrays, like the reference's
+    np.concatenate onto float64 zeros).  The reference walks the source in cfg.pc_eval_chamfer_num_parts pieces to
+    bound its [Ns,Nt,3] temporary; nothing of that size exists here, so the cloud goes through in one call."""
+    device = torch.device("cuda") if device is None else device
+    src = torch.from_numpy(np.ascontiguousarray(source_np)).to(device)
+    tgt = torch.from_numpy(np.ascontiguousarray(target_np)).to(device)
+    _, dist, idx = point_cloud_distance(src, tgt)
+    return dist.cpu().numpy().astype(np.float64), idx.cpu().numpy().astype(np.float64)
+
+
+def chamfer_distances(pred, gt):
+    """The two directed means the evaluation reports per view (eval_chamfer_to.py:119-123):
+    (mean_i min_j |pred_i - gt_j|, mean_j min_i |gt_j - pred_i|) as a float64 tensor [2] on the inputs' device."""
+    p2g = point_cloud_distance(pred, gt)[1]
+    g2p = point_cloud_distance(gt, pred)[1]
+    return torch.stack([p2g.double().mean(), g2p.double().mean()])

@@ -12,7 +12,7 @@ import torch
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "csrc"))
 LIB_PATH = os.path.join(_CSRC, "libdpc_render.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 DPC_MAX_TAPS = 63
 DPC_SMALL_COLS = 12
 COL_DQ, COL_DS, COL_DT, COL_DF = 0, 4, 5, 8
@@ -24,7 +24,7 @@ SYMBOLS = (
     "dpc_abi_version", "dpc_strerror", "dpc_mask_words_per_plane", "dpc_cells_bytes", "dpc_workspace_bytes", "dpc_locate",
     "dpc_project_fwd", "dpc_project_bwd", "dpc_project_loss_fwd", "dpc_project_loss_bwd", "dpc_transform_fwd", "dpc_transform_bwd",
     "dpc_splat_fwd", "dpc_splat_bwd", "dpc_smooth", "dpc_drc_fwd", "dpc_drc_bwd",
-    "dpc_silhouette_loss", "dpc_profile_enable", "dpc_profile_disable", "dpc_profile_count", "dpc_profile_get", "dpc_profile_pair_overhead",
+    "dpc_silhouette_loss", "dpc_nearest_workspace_bytes", "dpc_point_cloud_distance", "dpc_profile_enable", "dpc_profile_disable", "dpc_profile_count", "dpc_profile_get", "dpc_profile_pair_overhead",
 )
 
 
@@ -87,6 +87,10 @@ def lib():
         L.dpc_profile_pair_overhead.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
         L.dpc_silhouette_loss.restype = ctypes.c_int
         L.dpc_silhouette_loss.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
+        L.dpc_nearest_workspace_bytes.restype = ctypes.c_size_t
+        L.dpc_nearest_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.dpc_point_cloud_distance.restype = ctypes.c_int
+        L.dpc_point_cloud_distance.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp]
         L.dpc_smooth.restype = ctypes.c_int
         L.dpc_smooth.argtypes = [pp, vp, vp, ctypes.c_int, vp, vp, vp, vp]
         if L.dpc_abi_version() != ABI_VERSION:

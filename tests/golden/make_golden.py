@@ -375,8 +375,45 @@ def f8_f9_model_side():
     print("wrote f9_schedules.json", sched)
 
 
+def f11_nearest():
+    """point_cloud_distance (dpc/util/point_cloud_distance.py:25-40), the kernel of the Chamfer evaluation
+    (dpc/run/eval_chamfer_to.py:24-44, 119-123): nearest target point of every source point."""
+    import util.point_cloud_distance as ref_pcd
+
+    g = torch.Generator().manual_seed(4242)
+    cases = {}
+
+    def add(name, vs, vt):
+        proj, dist, idx = ref_pcd.point_cloud_distance(vs, vt)
+        cases[name + "_vs"], cases[name + "_vt"] = vs, vt
+        cases[name + "_proj"], cases[name + "_dist"], cases[name + "_idx"] = proj, dist, idx
+
+    add("f32", torch.rand(300, 3, generator=g) - 0.5, torch.rand(500, 3, generator=g) - 0.5)
+    add("f64", torch.rand(257, 3, generator=g, dtype=torch.float64) - 0.5,
+        torch.rand(1000, 3, generator=g, dtype=torch.float64) - 0.5)
+    # exact ties: points on a coarse lattice (many equal distances, first minimum must win), duplicates, zero distances
+    lat_t = torch.randint(-4, 5, (400, 3), generator=g).float() / 8
+    lat_s = torch.randint(-4, 5, (200, 3), generator=g).float() / 8
+    add("ties32", lat_s, torch.cat([lat_t, lat_t[:50]]))
+    add("ties64", lat_s.double(), torch.cat([lat_t, lat_t[:50]]).double())
+    add("one_target", torch.rand(17, 3, generator=g) - 0.5, torch.rand(1, 3, generator=g) - 0.5)
+    add("one_source", torch.rand(1, 3, generator=g) - 0.5, torch.rand(33, 3, generator=g) - 0.5)
+    # the evaluation's two directed means (eval_chamfer_to.py:119-123) on a pair of clouds
+    pred, gt = torch.rand(800, 3, generator=g, dtype=torch.float64) - 0.5, torch.rand(1500, 3, generator=g, dtype=torch.float64) - 0.5
+    p2g = ref_pcd.point_cloud_distance(pred, gt)[1]
+    g2p = ref_pcd.point_cloud_distance(gt, pred)[1]
+    cases["chamfer_pred"], cases["chamfer_gt"] = pred, gt
+    cases["chamfer_pair"] = np.array([p2g.numpy().mean(), g2p.numpy().mean()])
+    save("f11_nearest.npz", **cases)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
+    if len(sys.argv) > 1:  # regenerate only the named groups, e.g. `make_golden.py f11_nearest`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        assert not os.path.exists(os.path.join(REF, "dpc/util/__pycache__")), "left bytecode in the reference"
+        sys.exit(0)
     f1_gauss()
     f2_transform()
     f3_splat()
@@ -385,4 +422,5 @@ if __name__ == "__main__":
     f6_chain()
     f7_scripts()
     f8_f9_model_side()
+    f11_nearest()
     assert not os.path.exists(os.path.join(REF, "dpc/util/__pycache__")), "left bytecode in the reference"

@@ -568,6 +568,67 @@ def test_point_dropout_matches_reference_rng(R):
         assert torch.equal(out[b].cpu(), pts[b].cpu()[idx[b]])
 
 
+@pytest.mark.parametrize("name", ["f32", "f64", "ties32", "ties64", "one_target", "one_source"])
+def test_nearest_point_golden(R, name):
+    """point_cloud_distance against the reference's outputs (F11): indices exact (first minimum, lattice ties
+    included), nearest points exact, distances within 1 ulp (the reference's torch-CPU sqrt is not correctly rounded)."""
+    g = np.load(os.path.join(GOLDEN, "f11_nearest.npz"))
+    dt = torch.float64 if g[name + "_vs"].dtype == np.float64 else torch.float32
+    proj, dist, idx = R.point_cloud_distance(dev(g[name + "_vs"], dtype=dt), dev(g[name + "_vt"], dtype=dt))
+    assert idx.dtype == torch.int64 and dist.dtype == dt and proj.dtype == dt
+    assert np.array_equal(idx.cpu().numpy(), g[name + "_idx"])
+    assert np.array_equal(proj.cpu().numpy(), g[name + "_proj"])
+    ref = g[name + "_dist"]
+    assert (np.abs(dist.cpu().numpy() - ref) <= np.spacing(np.abs(ref))).all()
+
+
+@pytest.mark.parametrize("ns,nt,dt", [(1000, 3000, torch.float32), (777, 5001, torch.float64), (8000, 16000, torch.float32),
+                                      (5, 70000, torch.float64), (3000, 1, torch.float32)])
+def test_nearest_point_oracle(R, O, ns, nt, dt):
+    """Fresh seeds, sizes that exercise several target slices and ragged tiles: bit-exact against the oracle
+    (indices AND distances: both use a correctly rounded sqrt), plus properties that need no oracle."""
+    g = torch.Generator().manual_seed(ns * 7 + nt)
+    vs = (torch.rand(ns, 3, generator=g, dtype=dt) - 0.5)
+    vt = (torch.rand(nt, 3, generator=g, dtype=dt) - 0.5)
+    vt[nt // 2] = vt[0]  # a duplicate target: the first one must win whenever it is the nearest
+    vs[0] = vt[0]
+    proj, dist, idx = R.point_cloud_distance(vs.cuda(), vt.cuda())
+    i = idx.cpu()
+    assert int(i.min()) >= 0 and int(i.max()) < nt and int(i[0]) == 0 and float(dist[0]) == 0.0
+    assert torch.equal(proj.cpu(), vt[i])
+    if ns * nt <= 2e7:
+        _, od, oi = O.point_cloud_distance(vs, vt)
+        assert torch.equal(i, oi)
+        assert torch.equal(dist.cpu(), od)
+    else:  # full size: the returned neighbour is at the returned distance, and no sampled target is closer
+        d = (vt[i] - vs)
+        rec = torch.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2])
+        close(dist, rec, tol=1e-6, what="nearest: distance of the returned neighbour")
+        probe = vt[torch.randint(0, nt, (256,), generator=g)]
+        dd = torch.cdist(vs.double(), probe.double())
+        assert bool((dd.min(dim=1).values >= dist.cpu().double() * (1 - 1e-6)).all())
+
+
+def test_chamfer_pair_golden(R):
+    g = np.load(os.path.join(GOLDEN, "f11_nearest.npz"))
+    pair = R.chamfer_distances(dev(g["chamfer_pred"], dtype=torch.float64), dev(g["chamfer_gt"], dtype=torch.float64))
+    assert np.allclose(pair.cpu().numpy(), g["chamfer_pair"], rtol=1e-13, atol=0)
+    md, ix = R.compute_distance(None, g["chamfer_pred"], g["chamfer_gt"])
+    assert md.dtype == np.float64 and ix.dtype == np.float64 and md.shape == (g["chamfer_pred"].shape[0],)
+    assert np.isclose(md.mean(), g["chamfer_pair"][0], rtol=1e-13)
+
+
+def test_nearest_point_errors(R):
+    with pytest.raises(IndexError):
+        R.point_cloud_distance(torch.zeros(3, 3, device="cuda"), torch.zeros(0, 3, device="cuda"))
+    with pytest.raises(ValueError):
+        R.point_cloud_distance(torch.zeros(3, 2, device="cuda"), torch.zeros(4, 3, device="cuda"))
+    with pytest.raises(RuntimeError):
+        R.point_cloud_distance(torch.zeros(3, 3), torch.zeros(4, 3))
+    p, d, i = R.point_cloud_distance(torch.zeros(0, 3, device="cuda"), torch.zeros(4, 3, device="cuda"))
+    assert p.shape == (0, 3) and d.shape == (0,) and i.shape == (0,)
+
+
 def test_zz_error_report():
     """Not a check: writes the worst observed error per quantity to gpurun_out/ for DESIGN.md."""
     worst = {}

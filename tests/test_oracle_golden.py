@@ -246,3 +246,30 @@ def test_schedules():
     for step, v in sched.items():
         assert abs(O.get_smooth_sigma(cfg, int(step)) - v["sigma_rel"]) < 1e-12
         assert abs(O.get_dropout_prob(cfg, int(step)) - v["keep_prob"]) < 1e-12
+
+
+NEAREST_CASES = ["f32", "f64", "ties32", "ties64", "one_target", "one_source"]
+
+
+@pytest.mark.parametrize("name", NEAREST_CASES)
+def test_nearest_point(golden, name):
+    """F11: point_cloud_distance of the reference (point_cloud_distance.py:25-40).  Indices are index work: exact,
+    including the lattice cases full of ties (first minimum).  Distances: the reference's torch-CPU sqrt is a
+    vectorised approximation, the oracle's is correctly rounded -- at most 1 ulp apart."""
+    g = golden("f11_nearest.npz")
+    vs, vt = torch.from_numpy(g[name + "_vs"]), torch.from_numpy(g[name + "_vt"])
+    proj, dist, idx = O.point_cloud_distance(vs, vt)
+    assert idx.dtype == torch.int64 and dist.dtype == vs.dtype
+    assert np.array_equal(idx.numpy(), g[name + "_idx"])
+    assert np.array_equal(proj.numpy(), g[name + "_proj"])
+    ulp = np.spacing(np.abs(g[name + "_dist"]).astype(g[name + "_dist"].dtype))
+    assert (np.abs(dist.numpy() - g[name + "_dist"]) <= ulp).all()
+
+
+def test_chamfer_pair(golden):
+    """The evaluation's two directed means (eval_chamfer_to.py:119-123)."""
+    g = golden("f11_nearest.npz")
+    pred, gt = g["chamfer_pred"], g["chamfer_gt"]
+    p2g = O.point_cloud_distance(pred, gt)[1].numpy().mean()
+    g2p = O.point_cloud_distance(gt, pred)[1].numpy().mean()
+    assert np.allclose([p2g, g2p], g["chamfer_pair"], rtol=1e-14, atol=0)
