@@ -1,0 +1,97 @@
+"""One training step of the reference's unsupervised shape-and-pose model around dpc.render.
+
+Follows ModelPointCloud.forward / get_loss (dpc/models/model_pc_to.py:289-336, 339-408, 410-489) and the loop body
+of dpc/run/train_to.py:110-134 for the live configuration of the experiments (predict_pose, K pose candidates with a
+student, learned occupancy scale, no rgb / depth / drc losses, no translation, fixed focal length):
+
+    images [B*V,3,S,S] -> encoder -> ids [B*V,z]; the first view's id of every object -> decoder -> points [B,N,3]
+    pose FC of every image -> K candidate quaternions + 1 student quaternion per image
+    points, scales repeated V*K times (candidate-minor), optional point dropout
+    renderer + min-of-K silhouette loss in ONE call (dpc.render.pointcloud_project_loss)
+    student loss against the winning candidate, (proj + student) * proj_weight, backward, Adam
+"""
+import torch
+import torch.nn.functional as F
+
+import dpc.render as R
+
+from .nets import StepNets
+
+
+def pooled_masks(masks, size):
+    """[M,1,Hm,Wm] masks -> [M,size,size,1], average-pooled like add_proj_loss (model_pc_to.py:346-356)."""
+    if masks.shape[2] < size:
+        raise ValueError("GT size should not be smaller than the prediction size")
+    if masks.shape[2] > size:
+        masks = F.avg_pool2d(masks, masks.shape[2] // size)
+    return masks.permute(0, 2, 3, 1).contiguous()
+
+
+def student_loss(poses, student, winner, num_candidates, weight):
+    """add_student_loss (model_pc_to.py:442-489), rotation-difference form: 1 - <teacher, student>_w^2, teachers detached."""
+    teachers = poses.reshape(-1, num_candidates, 4)
+    rows = torch.arange(teachers.shape[0], device=poses.device)
+    teacher = teachers[rows, winner.long()].detach()
+    diff = R.quaternion_normalise(R.quaternion_multiply(teacher.double(), R.quaternion_conjugate(student.double())))
+    return (1.0 - diff[:, 0] ** 2).sum() / winner.shape[0] * weight
+
+
+def device_point_dropout(points, keep_prob, generator=None):
+    """pc_point_dropout (point_cloud_to.py:269-295) without the host: int(N*keep) distinct random points per cloud,
+    chosen by ranking device-side uniforms.  Same distribution as the reference's np.random.choice(replace=False),
+    different random stream (no numpy RNG, index upload or sync inside the step)."""
+    B, N = points.shape[0], points.shape[1]
+    keep = int(N * keep_prob)
+    idx = torch.rand(B, N, device=points.device, generator=generator).topk(keep, dim=1).indices
+    return points.gather(1, idx.unsqueeze(-1).expand(B, keep, 3))
+
+
+class TrainStep:
+    def __init__(self, cfg, device, lr=1e-4, device_dropout=False):
+        self.cfg, self.device, self.device_dropout = cfg, device, device_dropout
+        self.nets = StepNets(cfg).to(device)
+        self.optimizer = torch.optim.Adam(self.nets.parameters(), lr=lr, weight_decay=cfg.weight_decay)  # train_to.py:73-74
+        self.global_step = 0
+
+    def load_reference_state(self, state_dict):
+        self.nets.load_state_dict(state_dict)
+
+    def predict(self, images):
+        cfg, n = self.cfg, self.nets
+        enc = n.encoder(images)
+        first_view = enc["ids"][::cfg.step_size]  # pool_single_view(cfg, ids, 0), model_base_to.py:8-10
+        out = {"ids": enc["ids"], "points_1": n.decoder(first_view), "scaling_factor": n.scalePred(first_view)}
+        out.update(n.poseNet(enc["poses"]))
+        return out
+
+    def loss(self, images, masks, global_step=None):
+        """Forward of one step; returns (total loss, dict of the pieces the reference's outputs dict would hold)."""
+        cfg = self.cfg
+        step = self.global_step if global_step is None else global_step
+        out = self.predict(images)
+        K, V = cfg.pose_predict_num_candidates, cfg.step_size
+        all_points = out["points_1"].repeat_interleave(V * K, dim=0)          # tf_repeat_0 twice (:302-306)
+        all_scales = out["scaling_factor"].repeat_interleave(V * K, dim=0) if cfg.pc_learn_occupancy_scaling else None
+        if cfg.pc_point_dropout != 1:
+            keep = R.get_dropout_prob(cfg, step)
+            all_points = device_point_dropout(all_points, keep) if self.device_dropout else R.pc_point_dropout(all_points, None, keep)[0]
+        kernel = R.smoothing_kernel(cfg, R.get_smooth_sigma(cfg, step))
+        gt = pooled_masks(masks, cfg.vox_size)
+        proj_loss, proj_out, winner = R.pointcloud_project_loss(cfg, all_points, out["poses"], None, None, kernel,
+                                                                scaling_factor=all_scales, gt=gt, num_candidates=K)
+        total = proj_loss.double()
+        if K > 1 and cfg.pose_predictor_student:
+            out["student_loss"] = student_loss(out["poses"], out["pose_student"], winner, K, cfg.pose_predictor_student_loss_weight)
+            total = total + out["student_loss"]
+        total = total * cfg.proj_weight
+        out.update(projs=proj_out["proj"], min_loss=winner, proj_loss=proj_loss, pooled_masks=gt)
+        return total, out
+
+    def __call__(self, images, masks):
+        """zero_grad, forward, loss, backward, Adam step (train_to.py:112-131).  Returns the loss tensor (no host sync)."""
+        self.optimizer.zero_grad(set_to_none=True)
+        total, _ = self.loss(images, masks)
+        total.backward()
+        self.optimizer.step()
+        self.global_step += 1
+        return total.detach()

@@ -138,7 +138,7 @@ def quaternion_multiply(a, b):
 
 def quaternion_conjugate(q):
     """[w, -x, -y, -z] (dpc/util/quaternion.py:89-92)."""
-    return q * torch.tensor([1.0, -1.0, -1.0, -1.0], dtype=q.dtype, device=q.device)
+    return torch.cat((q[..., :1], -q[..., 1:]), dim=-1)  # no host constant: usable while a HIP graph is being captured
 
 
 def quaternion_normalise(q):

@@ -407,6 +407,58 @@ def f11_nearest():
     save("f11_nearest.npz", **cases)
 
 
+def f10_full_step():
+    """Tiny-config full training step through the reference's own ModelPointCloud (dpc/models/model_pc_to.py):
+    encoder -> decoder / pose candidates / scale -> projection -> min-of-K silhouette loss + student loss -> backward.
+    The renderer call inside the model is given the CUDA-branch semantics (ref_chain above: the reference's own
+    functions composed in the reference's order), because on this CPU-only host pointcloud_project_fast would skip
+    the Gaussian (point_cloud_to.py:206-212).  Stored: config, state_dict, inputs, the outputs a harness needs to
+    be checked against (points, poses, scales, silhouettes, winners, loss) and every parameter's gradient."""
+    sys.modules.setdefault("nets.net_factory", type(sys)("nets.net_factory")).get_network = None  # TF-era module, unused
+    import models.model_pc_to as ref_model
+
+    cfg = make_cfg(**yaml.safe_load(open(os.path.join(REF, "experiments/chair_unsupervised/config.yaml"))))
+    tiny = dict(z_dim=64, fc_dim=64, f_dim=8, pc_num_points=256, vox_size=16, pc_gauss_kernel_size=11, batch_size=2, step_size=2,
+                input_shape=[32, 32, 3], pc_point_dropout=1.0, pc_relative_sigma=1.5, align_to_canonical=False)
+    cfg.update(tiny)
+
+    def project(cfg_, pc, q, t, rgb, kernel, scaling_factor=None, focal_length=None):
+        out = ref_chain(cfg_, pc, q, t, kernel, scaling_factor, focal_length, smooth=True)
+        out["proj_rgb"] = None
+        return out
+
+    ref_model.pointcloud_project_fast = project
+    torch.manual_seed(77)
+    np.random.seed(77)
+    model = ref_model.ModelPointCloud(cfg)
+    with torch.no_grad():  # spread the pose candidates (at the reference's init they nearly coincide and candidate 0 always wins)
+        for prm in model.poseNet.parameters():
+            prm.add_(0.5 * torch.randn(prm.shape, generator=torch.Generator().manual_seed(prm.numel())))
+        # ... and the decoded shape away from the origin (an anisotropic cloud, so that the pose matters)
+        b = model.decoder.pts_raw_fc.bias
+        b.add_((torch.randn(b.shape, generator=torch.Generator().manual_seed(5)).reshape(-1, 3) * torch.tensor([0.9, 0.5, 0.2])).reshape(-1))
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(78)
+    nimg = cfg.batch_size * cfg.step_size
+    images = torch.rand(nimg, 3, 32, 32, generator=g)
+    masks = (torch.rand(nimg, 1, 32, 32, generator=g) > 0.5).float()
+    inputs = dict(images=images, masks=masks.clone(), images_1=images[::cfg.step_size])
+    with quiet():
+        outputs = model(inputs, 0, is_training=True, run_projection=True)
+        loss, min_loss = model.get_loss(inputs, outputs, add_summary=False)
+    loss.backward()
+    arrays = {"state/" + k: v for k, v in state.items()}
+    arrays.update({"grad/" + k: p.grad for k, p in model.named_parameters() if p.grad is not None})
+    arrays["no_grad"] = np.array([k for k, p in model.named_parameters() if p.grad is None])
+    arrays.update(images=images, masks=masks, points_1=outputs["points_1"], poses=outputs["poses"],
+                  pose_student=outputs["pose_student"], scaling_factor=outputs["scaling_factor"], projs=outputs["projs"],
+                  pooled_masks=inputs["masks"], loss=loss.detach(), min_loss=min_loss)
+    save("f10_full_step.npz", **arrays)
+    json.dump({k: (v if not isinstance(v, np.generic) else v.item()) for k, v in cfg.items()},
+              open(os.path.join(HERE, "f10_config.json"), "w"), indent=0, sort_keys=True, default=str)
+    print("wrote f10_config.json; loss", float(loss), "winners", min_loss.tolist())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1:  # regenerate only the named groups, e.g. `make_golden.py f11_nearest`
@@ -423,4 +475,5 @@ if __name__ == "__main__":
     f7_scripts()
     f8_f9_model_side()
     f11_nearest()
+    f10_full_step()
     assert not os.path.exists(os.path.join(REF, "dpc/util/__pycache__")), "left bytecode in the reference"
