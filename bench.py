@@ -142,6 +142,8 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE config (default c2 = the metric's)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a single-GPU box: every rank uses cuda:0 and the collectives run over gloo")
     args = ap.parse_args()
     global B, N_PTS, G, SIGMA_REL, K_CAND
     B, N_PTS, G, SIGMA_REL, K_CAND = CONFIGS[args.config]
@@ -153,11 +155,16 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in dpc.render)")
+    if args.rehearse_on_one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
 
     import dpc.render as R
     from dpc.render import _native
