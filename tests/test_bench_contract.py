@@ -1,0 +1,36 @@
+"""Host-side checks of bench.py's bookkeeping (no GPU): the contractual byte counts of SURVEY.md 8(d), the kernel byte
+table, and the CPU baseline's shape."""
+import importlib.util
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_algorithmic_bytes_match_survey():
+    b = _bench()
+    assert b.algorithmic_bytes_per_cloud(8000, 64) == 10_013_952     # c2 / c5
+    assert b.algorithmic_bytes_per_cloud(16000, 128) == 76_716_544   # c4
+    # 60 % of 8 TB/s at c2 = the target quoted in BASELINE.json's north star
+    assert round(0.6 * 8.0e12 / b.algorithmic_bytes_per_cloud(8000, 64)) == 479_332
+
+
+def test_kernel_byte_table_is_below_the_contract():
+    """This implementation moves fewer bytes than A(N,G) (two grids of the reference chain never reach HBM)."""
+    b = _bench()
+    kb = b.kernel_bytes_per_cloud(8000, 64)
+    fused_step = kb["k_locate"] + kb["k_splat_hw"] + kb["k_zcol_fwdbwd"] + kb["k_gather_hw"]
+    assert fused_step < b.algorithmic_bytes_per_cloud(8000, 64)
+    assert set(b.CONFIGS) == {"c2", "c4", "c5"} and b.CONFIGS["c2"][:3] == (32, 8000, 64)
+
+
+def test_measured_traffic_reads_the_committed_profile():
+    b = _bench()
+    t = b.measured_traffic("k_splat_hw")
+    assert t is None or 1e6 < t < 1e9

@@ -77,3 +77,74 @@ def test_shard_ranges_cover_everything():
             r = [shard_samples(n, k, w) for k in range(w)]
             assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
             assert max(e - b for b, e in r) - min(e - b for b, e in r) <= 1
+
+
+# ------------------------------------------------------------------------------------------------------
+# The same exchange with the real parameter set: the harness networks (tests/test_harness.py), whose colour and
+# focal heads get no gradient (such tensors must be zero-filled, not skipped, or ranks disagree
+# on the bucket layout).  The renderer is replaced by the oracle on a tiny grid.
+# ------------------------------------------------------------------------------------------------------
+def _harness_problem():
+    import json
+
+    from dpc.harness import StepNets, pooled_masks
+
+    class C(dict):
+        __getattr__ = dict.__getitem__
+
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    cfg = C(json.load(open(os.path.join(golden, "f10_config.json"))))
+    cfg.update(batch_size=4, vox_size=8, pc_gauss_kernel_size=3)
+    torch.manual_seed(11)
+    nets = StepNets(cfg)
+    g = torch.Generator().manual_seed(12)
+    n = cfg.batch_size * cfg.step_size
+    images, masks = torch.rand(n, 3, 32, 32, generator=g), (torch.rand(n, 1, 32, 32, generator=g) > 0.5).float()
+    return cfg, nets, images, pooled_masks(masks, cfg.vox_size)
+
+
+def _harness_loss(cfg, nets, images, gt, lo, hi):
+    """objects [lo, hi): networks -> oracle renderer -> min-of-K loss (mean over the rank's own samples)."""
+    V, K = cfg.step_size, cfg.pose_predict_num_candidates
+    enc = nets.encoder(images[lo * V:hi * V])
+    first = enc["ids"][::V]
+    pts = nets.decoder(first).repeat_interleave(V * K, dim=0)
+    scale = nets.scalePred(first).repeat_interleave(V * K, dim=0)
+    poses = nets.poseNet(enc["poses"])["poses"]
+    ocfg = O.Cfg(vox_size=cfg.vox_size, pc_gauss_kernel_size=cfg.pc_gauss_kernel_size)
+    out = O.pointcloud_project_fast(ocfg, pts, poses, None, None, O.smoothing_kernel(ocfg, 0.8), scaling_factor=scale)
+    return O.proj_loss_pose_candidates(gt[lo * V:hi * V].double(), out["proj"], K)[0]
+
+
+def _harness_worker(rank, world, port, ret):
+    from dpc.render.parallel import BucketedGradAllReduce, shard_samples
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg, nets, images, gt = _harness_problem()
+        lo, hi = shard_samples(cfg.batch_size, rank, world)
+        _harness_loss(cfg, nets, images, gt, lo, hi).backward()
+        missing = sorted(k for k, p in nets.named_parameters() if p.grad is None)
+        BucketedGradAllReduce(nets.parameters(), bucket_mb=0.05)((hi - lo) * cfg.step_size, cfg.batch_size * cfg.step_size)
+        ret[rank] = dict(missing=missing, grads={k: p.grad.clone() for k, p in nets.named_parameters()})
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradients_of_the_real_networks():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_harness_worker, args=(2, port, ret), nprocs=2, join=True)
+    cfg, nets, images, gt = _harness_problem()
+    _harness_loss(cfg, nets, images, gt, 0, cfg.batch_size).backward()
+    assert any(k.startswith("decoder.rgb") for k in ret[0]["missing"]) and "focalPred.fc.weight" in ret[0]["missing"]
+    for r in (0, 1):
+        for k, p in nets.named_parameters():
+            g = ret[r]["grads"][k]
+            if p.grad is None:
+                assert float(g.abs().max()) == 0.0, k  # zero-filled, took part in the exchange
+            else:
+                assert torch.allclose(g, p.grad, rtol=1e-4, atol=1e-6 * float(p.grad.abs().max())), k
