@@ -329,6 +329,11 @@ template <int GS, int RB, int NT_, int LW_, int LH_>
 struct SlabGeo {
   static constexpr int PAD = RB <= 4 ? 4 : ((RB + 3) / 4) * 4;
   static constexpr int WP = GS + PAD;
+  // row stride of the forward's 64-bit accumulators (u64 units).  GS + PAD is a multiple of 4, i.e. 8 mod 16 dwords:
+  // lanes that walk rows with ds_read_b128 then use only every other group of four banks (2-way conflict in every
+  // 16-lane group; SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE).  Two spare (always zero) entries per row make
+  // the stride 4 or 12 mod 16 dwords: sixteen consecutive rows land on sixteen distinct bank groups.
+  static constexpr int WPA = GS + PAD + 2;
   static constexpr int PLANE = GS * WP;
   static constexpr int LW = LW_, NSEGW = GS / LW, LWIN = LW + 2 * PAD;              // W-pass
   static constexpr int LH = LH_, NSEGH = GS / LH, XP = GS / 2, HWIN = LH + 2 * RB;  // H-pass
@@ -539,7 +544,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
     // Accumulator rows carry the same zero pads as the fp32 slab rows ([PAD][GS] u64), so the W-pass can take its
     // windows straight from the accumulators.
     using Geo = FwdGeo<GS, ZS, RB>;
-    constexpr int WPA = GS + Geo::PAD;                       // accumulator row stride (u64)
+    constexpr int WPA = Geo::WPA;                            // accumulator row stride (u64), see SlabGeo
     constexpr int ACC = ZS * GS * WPA + Geo::PAD;            // u64 words incl. the tail pad
     constexpr int VOX = ZS * GS * GS, VPT = VOX / Geo::NT;
     static_assert(VOX % Geo::NT == 0 && Geo::NT % 64 == 0 && (GS * GS) % 64 == 0 && ACC % 2 == 0, "slab shape");
@@ -1592,7 +1597,7 @@ template <int GS, int ZS, int RB>
 int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
                       uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st) {
   using Geo = FwdGeo<GS, ZS, RB>;
-  constexpr size_t lds = ((size_t)ZS * GS * (GS + Geo::PAD) + Geo::PAD) * sizeof(unsigned long long) + kTabInts * sizeof(int);
+  constexpr size_t lds = ((size_t)ZS * GS * Geo::WPA + Geo::PAD) * sizeof(unsigned long long) + kTabInts * sizeof(int);
   static_assert(lds >= Geo::slab_floats(ZS) * sizeof(float), "the fp32 slab reuses the accumulator memory");
   static_assert(lds <= kLdsLimit, "forward slab does not fit LDS");
   auto kern = k_splat_hw<GS, ZS, RB>;
