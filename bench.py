@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP graph replay")
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the median/best windows and the forward-only timing "
+                    "(profiling runs: keeps every traced kernel inside the contract's fwd+bwd step)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE config (default c2 = the metric's)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single-GPU box: every rank uses cuda:0 and the collectives run over gloo")
@@ -269,7 +271,7 @@ def main():
         # SURVEY 8(d) extras on rank 0, outside the contract's timed region: median / best step over short windows, and
         # the forward alone (no_grad: locate, slab kernel, ray march with the loss)
         extras = {}
-        if rank == 0 and graph is not None:
+        if rank == 0 and graph is not None and not args.no_extras:
             def window_us(replay, n):
                 a, b_ = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record(side)

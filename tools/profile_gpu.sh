@@ -4,7 +4,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_final; rm -rf $OUT; mkdir -p $OUT
-BENCH="python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline"
+BENCH="python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1; echo "trace exit=$?"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $BENCH --no-graph > $OUT/fetch.log 2>&1; echo "fetch exit=$?"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $BENCH --no-graph > $OUT/write.log 2>&1; echo "write exit=$?"

@@ -4,7 +4,7 @@
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/pmc; rm -rf $OUT; mkdir -p $OUT
-BENCH="python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-graph"
+BENCH="python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --no-graph"
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_INST_CYCLES_VMEM SQ_WAIT_ANY"; do
   i=$((i+1))
