@@ -904,7 +904,7 @@ __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_fwd(Dp
 //   dL/dv3 = g T / (1 - y) (+ g (e^eps - 1) for the first voxel),  dL/ds = sum y dL/dv3 / s  (inside: v2 = y / s)
 // RPL = rays per lane: neighbouring rays x .. x+RPL-1 (RPL divides W, so they share an image row).
 template <int DD, int RB, int RPL>
-__global__ __launch_bounds__(kColThreads, (RPL * DD <= 64 ? 2 : 1))
+__global__ __launch_bounds__(kColThreads, (RPL * DD <= 128 ? 2 : 1))
 void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, const float* __restrict__ s, TapsT<RB> taps,
                    TapsT<RB> taps_adj, float* __restrict__ proj, float* __restrict__ dT, float* __restrict__ ds_part,
                    int n_ds_part, unsigned long long* __restrict__ tickets, float* __restrict__ dsmall, LossArgs la) {
@@ -1618,6 +1618,9 @@ int launch_splat(const DpcParams* p, Cells cells, const float* kxy, const TapPla
     }
     if constexpr (RB <= 10) {
       if (p->H == 64) return launch_splat_fast<64, kFwdZs64, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
+      if constexpr (RB > 4) {
+        if (p->H == 128) return launch_splat_fast<128, 1, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
+      }
     }
   }
   const int fit = planes_fit(p);
@@ -1660,6 +1663,7 @@ int launch_gather(const DpcParams* p, Cells cells, const float* pc, const float*
       if (p->H == 64) return launch_gather_fast<64, kBwdZs64, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
     } else if constexpr (RB <= 10) {
       if (p->H == 64) return launch_gather_fast<64, 7, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
+      if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);  // c4: sigma_rel 1.28 -> radius 8
     }
   }
   const int fit = planes_fit(p);
@@ -1728,12 +1732,12 @@ int dpc_splat_fwd(const DpcParams* p, const void* tr, int tr_is_f64, void* cells
 
 namespace {
 
-// k_zcol_fwdbwd handles one pose candidate per sample, 32- or 64-deep columns with a bucketed z kernel; with two rays
+// k_zcol_fwdbwd handles one pose candidate per sample, 32-, 64- or 128-deep columns with a bucketed z kernel; with two rays
 // per lane its accesses are float2: an even image width and 8-byte aligned grids/images.
 bool can_fuse_column_backward(const DpcParams* p, const TapPlan& pz, int K, const void* grid_wh, const void* proj,
                               const void* gt, const void* workspace) {
   const auto aligned8 = [](const void* ptr) { return (reinterpret_cast<uintptr_t>(ptr) & 7u) == 0; };
-  return K == 1 && gt != nullptr && p->B > 0 && pz.bucket >= 0 && (p->D == 32 || p->D == 64) && p->W % DPC_ZFB_RPL == 0 &&
+  return K == 1 && gt != nullptr && p->B > 0 && pz.bucket >= 0 && (p->D == 32 || p->D == 64 || p->D == 128) && p->W % DPC_ZFB_RPL == 0 &&
          aligned8(grid_wh) && aligned8(proj) && aligned8(gt) && aligned8(workspace);
 }
 
@@ -1777,7 +1781,8 @@ int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const 
   {                                                                                                                \
     const TapsT<RB> tzf = make_taps<RB>(host_kern_z, pz, false), tza = make_taps<RB>(host_kern_z, pz, true);       \
     if (p->D == 32) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<32, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, bwd_dsmall, la); \
-    else DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<64, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, bwd_dsmall, la); \
+    else if (p->D == 64) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<64, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, bwd_dsmall, la); \
+    else DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<128, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, bwd_dsmall, la); \
   }
     DPC_FOR_BUCKET(pz.bucket, LAUNCH_ZFB)
 #undef LAUNCH_ZFB
