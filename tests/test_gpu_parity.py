@@ -427,6 +427,32 @@ def test_project_loss_fused(R, O, K):
         assert gq.grad[torch.from_numpy(lose).cuda()].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("B,N,G,ksz,sig", [(37, 700, 32, 11, 1.2), (19, 1500, 64, 21, 0.64), (3, 2500, 64, 21, 3.0)])
+def test_project_loss_fused_shapes(R, O, B, N, G, ksz, sig):
+    """The one-candidate fused step (column backward inside the forward, 64-bit sum-and-count words per cloud) on batch
+    sizes and kernels that are not the benchmark's: odd B, both grid sizes, a short and a full-length Gaussian; called
+    twice on the same buffers (the per-cloud words must come back to zero), backward with a non-unit upstream factor."""
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=ksz)
+    pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 900 + B)
+    leaf = lambda x: x.clone().requires_grad_(True)
+    cp, cq, cs = leaf(pc), leaf(q), leaf(s)
+    ref = O.pointcloud_project_fast(cfg, cp, cq, None, None, O.smoothing_kernel(cfg, sig), scaling_factor=cs)
+    rloss = ((ref["proj"] - gt) ** 2).sum() / B
+    (0.5 * rloss).backward()
+    gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+    for rep in range(2):
+        gp.grad = gq.grad = gs.grad = None
+        loss, out, win = R.pointcloud_project_loss(cfg, gp, gq, None, None, R.smoothing_kernel(cfg, sig), scaling_factor=gs,
+                                                   gt=dev(gt), num_candidates=1)
+        (0.5 * loss).backward()
+        assert int(win.abs().max()) == 0
+        close(loss, rloss, TOL, "fused K=1 loss B=%d G=%d rep %d" % (B, G, rep))
+        close(out["proj"], ref["proj"], TOL, "fused K=1 proj")
+        close(gp.grad, cp.grad, TOL, "fused K=1 dpc")
+        close(gq.grad, cq.grad, 3e-5, "fused K=1 dq")
+        close(gs.grad, cs.grad, 3e-5, "fused K=1 ds")
+
+
 def test_config4_full_size(R, O):
     """BASELINE config 4 per-GPU shard: 8 clouds x 16000 pts -> 128^3, sigma = 0.01 (sigma_rel 1.28), 21 taps.
     Size-independent properties on all 8 clouds + the oracle on one of them (128^3 fp64 on CPU takes seconds)."""
