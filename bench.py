@@ -144,6 +144,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the median/best windows and the forward-only timing "
                     "(profiling runs: keeps every traced kernel inside the contract's fwd+bwd step)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE config (default c2 = the metric's)")
+    ap.add_argument("--api", choices=["fused", "plain"], default="fused",
+                    help="fused: pointcloud_project_loss (renderer + loss in one autograd node, the default and the contract "
+                         "line); plain: the reference's own call sequence, pointcloud_project_fast then the loss in torch")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single-GPU box: every rank uses cuda:0 and the collectives run over gloo")
     args = ap.parse_args()
@@ -194,6 +197,15 @@ def main():
 
     def step():
         # projection + sum((proj-gt)^2)/B in one autograd node (loss folded into the ray-march kernels)
+        if ns == 1 and args.api == "plain":  # what ModelPointCloud does: compute_projection, then add_proj_loss in torch
+            pc.grad = q.grad = s.grad = None
+            proj = R.pointcloud_project_fast(cfg, pc, q, None, None, kern, scaling_factor=s)["proj"]
+            if K_CAND > 1:
+                loss, _ = R.silhouette_loss(proj, gt, K_CAND)
+            else:
+                loss = ((proj - gt) ** 2).sum() / B
+            loss.backward(gradient=one)
+            return loss
         if ns == 1:
             pc.grad = q.grad = s.grad = None
             loss, _, _ = R.pointcloud_project_loss(cfg, pc, q, None, None, kern, scaling_factor=s, gt=gt, num_candidates=K_CAND)
@@ -323,7 +335,7 @@ def main():
                                   2 * G, 2 * G, "loss sum((proj-gt)^2)/B" if K_CAND == 1 else
                                   "min-of-%d pose-candidate loss" % K_CAND),
                    "clouds_per_gpu": B, "points": N_PTS, "grid": G, "taps": KSIZE, "sigma_rel": SIGMA_REL,
-                   "launch": "eager" if graph is None else "hip-graph replay", "streams": ns,
+                   "launch": "eager" if graph is None else "hip-graph replay", "streams": ns, "api": args.api,
                    "sharding": "clouds, no collective"},
         "roofline": roofline,
         "roofline_step": {"bound": "hbm", "achieved": step_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

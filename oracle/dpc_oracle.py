@@ -10,7 +10,7 @@ module is the reference's backward and (ii) timing it on the GPU box's host stan
 PyTorch CPU path" (the reference itself cannot travel).
 
 Parity is PINNED: tests/test_oracle_golden.py checks every function here against golden vectors produced by
-importing and running the reference in the build container (tests/golden/make_golden.py, fixtures F1-F9),
+importing and running the reference in the build container (tests/golden/make_golden.py, fixtures F1-F11),
 including the two seed-0 script bodies the reference ships (dpc/run/pc_project_test.py,
 dpc/run/pc_full_proj_test.py).
 
