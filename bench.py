@@ -233,7 +233,8 @@ def main():
         side.synchronize()
         if not args.no_graph:
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
+            # thread_local: RCCL's watchdog thread may make HIP calls of its own while this thread captures
+            with torch.cuda.graph(graph, stream=side, capture_error_mode="thread_local"):
                 static_loss = step()
 
         last = [static_loss if graph is not None else None]
@@ -302,7 +303,7 @@ def main():
                 fwd_only()
             side.synchronize()
             fgraph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(fgraph, stream=side):
+            with torch.cuda.graph(fgraph, stream=side, capture_error_mode="thread_local"):
                 fwd_only()
             fw = sorted(window_us(fgraph.replay, 20) for _ in range(15))
             extras["forward_only_us"] = {"median": fw[len(fw) // 2], "best": fw[0]}
