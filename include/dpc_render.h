@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DPC_ABI_VERSION 8
+#define DPC_ABI_VERSION 9
 #define DPC_MAX_TAPS 63 /* longest 1-D smoothing kernel accepted (pc_gauss_kernel_size) */
 
 enum {
@@ -56,6 +56,12 @@ typedef struct DpcParams {
   float focal_length;      /* cfg.focal_length, used when f == NULL                                      */
   float clip_val;          /* cfg.drc_logsum_clip_val (eps)                                              */
   float max_depth;         /* cfg.max_depth                                                              */
+  int32_t point_replicas;  /* R: clouds b*R .. b*R+R-1 share point set b (tf_repeat_0 of the decoded points over views and
+                            * pose candidates, dpc/models/model_pc_to.py:302-306) -- then `pc` is [B/R,N,3], read once per
+                            * replica instead of being materialised B times, and `dpc` is [B/R,N,3], ZERO-INITIALISED BY
+                            * THE CALLER: the replicas' gradients are added into it.  0 or 1: every cloud has its own
+                            * points.  Honoured by the fused entry points (dpc_project_*); the stage entry points require
+                            * R <= 1. */
 } DpcParams;
 
 /* Small per-cloud gradients written by the backward entry points: one buffer of DPC_SMALL_COLS * B floats made of

@@ -195,7 +195,8 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
     const size_t idx = (size_t)b * P.N + i;
     double Z, Y, X;
     if (SRC == 0) {
-      const float* p = static_cast<const float*>(pts) + idx * 3;
+      const int reps = P.point_replicas > 1 ? P.point_replicas : 1;  // replicas of one point set read the same rows
+      const float* p = static_cast<const float*>(pts) + ((size_t)(b / reps) * P.N + i) * 3;
       src_pt[0] = p[0]; src_pt[1] = p[1]; src_pt[2] = p[2];
       project_point_ref(cam_s, p[0], p[1], p[2], Z, Y, X);
       if (tr_pc != nullptr) {
@@ -649,7 +650,10 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
           for (int e = 0; e < 2; ++e) {
             const int idx = 2 * k + e;
             if (idx >= Geo::PAD && idx < Geo::PAD + Geo::LW) bits |= (a2[e] <= kFixOne ? 1u : 0u) << (idx - Geo::PAD);
-            v[idx] = fminf(to_float(a2[e]), 1.0f);
+            const float fv = to_float(a2[e]);
+            if (raw != nullptr && idx >= Geo::PAD && idx < Geo::PAD + Geo::LW && row / GS < nz)  // optional output: the unclamped splat
+              raw[((size_t)b * D + z0) * HW + (size_t)row * GS + seg * Geo::LW + (idx - Geo::PAD)] = fv;
+            v[idx] = fminf(fv, 1.0f);
           }
         }
       }
@@ -1264,7 +1268,13 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   const int D = P.D, H = P.H, W = P.W, N = P.N, HW = H * W;
   const int Zs = GS ? ZS : zs_rt;
   const int b = blockIdx.y, z0 = blockIdx.x * Zs;
+  const int reps = P.point_replicas > 1 ? P.point_replicas : 1;
+  const bool shared_points = reps > 1;  // dpc is [B/reps,N,3], zeroed by the caller; replicas add into it
   if (cloud_loses(la, b)) {  // a losing pose candidate: zero gradient, no work (block-uniform)
+    if (shared_points) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) dsmall[(size_t)DPC_COL_DS * P.B + b] = 0.f;
+      return;
+    }
     float* dz = dpc + (size_t)b * N * 3;
     auto zero3 = [&](const PointRec&, const int4* aux) {
       const int i = aux->w;
@@ -1377,7 +1387,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   const Camera cam = make_camera(P, cam_raw);
   CamGrad g;
   camgrad_zero(g);
-  float* dcloud = dpc + (size_t)b * N * 3;
+  float* dcloud = dpc + (size_t)(b / reps) * N * 3;
   auto corner = [&](int zz, int yy, int xx) -> float {
     if constexpr (GS > 0) return slab[BwdGeo<GS, RB, ZS + 1>::at(zz, yy, xx)];
     else return slab[(zz * H + yy) * odd_stride(W) + xx];
@@ -1438,14 +1448,18 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     const Projected o = project_point(cam, px, py, pz);
     float dpx, dpy, dpz;
     project_point_bwd(cam, o, px, py, pz, dgz * (float)(D - 1), dgy * (float)(H - 1), dgx * (float)(W - 1), dpx, dpy, dpz, g);
-    dcloud[3 * i + 0] = dpx; dcloud[3 * i + 1] = dpy; dcloud[3 * i + 2] = dpz;
+    if (shared_points) {
+      atomicAdd(dcloud + 3 * i + 0, dpx); atomicAdd(dcloud + 3 * i + 1, dpy); atomicAdd(dcloud + 3 * i + 2, dpz);
+    } else {
+      dcloud[3 * i + 0] = dpx; dcloud[3 * i + 1] = dpy; dcloud[3 * i + 2] = dpz;
+    }
   };
   if (!DPC_ABL(10)) {
     if (GS > 0 && cells.nblk <= DPC_WAVE) for_each_record_flat(cells, b, reinterpret_cast<const int*>(red + kRedTab), gather);
     else for_each_record(cells, b, z0, min(z0 + Zs, D), gather);
   }
   DPC_STAMP(11);
-  if (blockIdx.x == 0)
+  if (blockIdx.x == 0 && !shared_points)
     for_each_record(cells, b, D, D + 1, [&](const PointRec&, const int4* aux) {
       const int i = aux->w;
       dcloud[3 * i + 0] = 0.f; dcloud[3 * i + 1] = 0.f; dcloud[3 * i + 2] = 0.f;
@@ -1541,6 +1555,7 @@ int validate(const DpcParams* p) {
   if (p == nullptr) return DPC_ERR_NULL;
   if (p->B < 0 || p->N < 0 || p->D < 1 || p->H < 1 || p->W < 1) return DPC_ERR_SHAPE;
   if (p->D > 1024 || p->H > 1024 || p->W > 1024 || p->B > 65535) return DPC_ERR_SHAPE;  // 10-bit cell indices
+  if (p->point_replicas < 0 || (p->point_replicas > 1 && p->B % p->point_replicas != 0)) return DPC_ERR_SHAPE;
   for (int taps : {p->taps_xy, p->taps_z})
     if (taps < 0 || taps > DPC_MAX_TAPS || (taps > 0 && taps % 2 == 0)) return DPC_ERR_TAPS;
   return DPC_OK;
@@ -1620,6 +1635,7 @@ int launch_splat(const DpcParams* p, Cells cells, const float* kxy, const TapPla
       if (p->H == 64) return launch_splat_fast<64, kFwdZs64, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
       if constexpr (RB > 4) {
         if (p->H == 128) return launch_splat_fast<128, 1, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
+        if (p->H == 32) return launch_splat_fast<32, 4, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
       }
     }
   }
@@ -1664,6 +1680,7 @@ int launch_gather(const DpcParams* p, Cells cells, const float* pc, const float*
     } else if constexpr (RB <= 10) {
       if (p->H == 64) return launch_gather_fast<64, 7, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
       if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);  // c4: sigma_rel 1.28 -> radius 8
+      if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
     }
   }
   const int fit = planes_fit(p);

@@ -70,11 +70,13 @@ class TrainStep:
         step = self.global_step if global_step is None else global_step
         out = self.predict(images)
         K, V = cfg.pose_predict_num_candidates, cfg.step_size
-        all_points = out["points_1"].repeat_interleave(V * K, dim=0)          # tf_repeat_0 twice (:302-306)
         all_scales = out["scaling_factor"].repeat_interleave(V * K, dim=0) if cfg.pc_learn_occupancy_scaling else None
         if cfg.pc_point_dropout != 1:
-            keep = R.get_dropout_prob(cfg, step)
+            all_points = out["points_1"].repeat_interleave(V * K, dim=0)      # tf_repeat_0 twice (:302-306)
+            keep = R.get_dropout_prob(cfg, step)                              # every replica drops its own points
             all_points = device_point_dropout(all_points, keep) if self.device_dropout else R.pc_point_dropout(all_points, None, keep)[0]
+        else:
+            all_points = out["points_1"]  # [B,N,3] shared by the V*K clouds of an object: the renderer reads it in place
         kernel = R.smoothing_kernel(cfg, R.get_smooth_sigma(cfg, step))
         gt = pooled_masks(masks, cfg.vox_size)
         proj_loss, proj_out, winner = R.pointcloud_project_loss(cfg, all_points, out["poses"], None, None, kernel,

@@ -256,6 +256,8 @@ class ProjectionOutputs(dict):
 
 def _project_staged(cfg, geom, pc, q, t, f, s, smooth):
     """The same chain composed from the stage-level kernels (all differentiable)."""
+    if pc.shape[0] != q.shape[0]:  # shared point sets: the stage kernels want one cloud per pose
+        pc = pc.repeat_interleave(q.shape[0] // pc.shape[0], dim=0)
     tr = Transform.apply(pc, q, t, f, geom)
     raw = Splat.apply(tr, geom)
     vox = torch.clamp(raw, 0.0, 1.0)
@@ -276,7 +278,12 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation, 
 
     Same positional signature as the reference; returns a dict with the reference's keys
     (proj, voxels, tr_pc, voxels_rgb, proj_rgb, drc_probs, proj_depth).  `smooth=False` reproduces the
-    reference's CPU branch, which skips the Gaussian (:210-212)."""
+    reference's CPU branch, which skips the Gaussian (:210-212).
+
+    Shared point sets: `point_cloud` may be [B/R,N,3] while `transform` (and the other per-cloud
+    inputs) have B rows -- clouds b*R .. b*R+R-1 then use point set b, the layout tf_repeat_0 produces for the views and
+    pose candidates of one object (dpc/models/model_pc_to.py:302-306), without materialising the B copies; the
+    gradient comes back as [B/R,N,3], summed over the replicas inside the backward kernel."""
     if all_rgb is not None:
         raise NotImplementedError("all_rgb: the rgb branch of the reference is dead (point_cloud_to.py:64 AttributeError)")
     _check_live_branches(cfg)
@@ -308,7 +315,7 @@ def pointcloud_project_loss(cfg, point_cloud, transform, predicted_translation, 
     S*num_candidates clouds (candidate-minor, like tf_repeat_0).  Returns (loss, outputs, winner): the scalar
     loss sum_s min_k sum (gt-pred)^2 / S, the usual output dict (`proj` from this pass, the rest lazy), and the
     winning candidate per sample.  Falls back to pointcloud_project_fast + silhouette_loss when the Gaussian is
-    too long for the fused kernels."""
+    too long for the fused kernels.  `point_cloud` may hold shared point sets ([B/R,N,3], see pointcloud_project_fast)."""
     if all_rgb is not None:
         raise NotImplementedError("all_rgb: the rgb branch of the reference is dead (point_cloud_to.py:64 AttributeError)")
     if gt is None:

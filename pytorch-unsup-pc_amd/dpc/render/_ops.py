@@ -30,10 +30,10 @@ class Geometry:
         self.camera_distance, self.focal_length = float(camera_distance), float(focal_length)
         self.clip_val, self.max_depth = float(clip_val), float(max_depth)
 
-    def params(self, B, Npts):
+    def params(self, B, Npts, point_replicas=1):
         return N.DpcParams(int(B), int(Npts), self.D, self.H, self.W,
                            0 if self.kxy is None else self.kxy.size, 0 if self.kz is None else self.kz.size,
-                           self.camera_distance, self.focal_length, self.clip_val, self.max_depth)
+                           self.camera_distance, self.focal_length, self.clip_val, self.max_depth, int(point_replicas))
 
     def kern_ptrs(self):
         if self.kxy is None:
@@ -43,6 +43,16 @@ class Geometry:
 
 def _f32(t):
     return None if t is None else t.detach().to(torch.float32).contiguous()
+
+
+def _replicas(pc, q):
+    """Clouds per point set: pc [S,N,3] shared by consecutive groups of B/S rows of q [B,4] (tf_repeat_0 order)."""
+    B, S = q.shape[0], pc.shape[0]
+    if S == B:
+        return 1
+    if S == 0 or B % S:
+        raise ValueError("%d poses cannot share %d point sets: the number of clouds must be a multiple" % (B, S))
+    return B // S
 
 
 def _meta(t):
@@ -123,8 +133,8 @@ class ProjectFused(torch.autograd.Function):
         dev = N.require_device(pc, q, t, f, s)
         L = N.lib()
         pc32, q32, t32, f32, s32 = _f32(pc), _f32(q), _f32(t), _f32(f), _f32(s)
-        B, Npts = pc32.shape[0], pc32.shape[1]
-        P = geom.params(B, Npts)
+        B, Npts, reps = q32.shape[0], pc32.shape[1], _replicas(pc32, q32)
+        P = geom.params(B, Npts, reps)
         wpp = L.dpc_mask_words_per_plane(ctypes.byref(P))
         grid_wh = torch.empty((B, geom.D, geom.H, geom.W), dtype=torch.float32, device=dev)
         mask = torch.empty((B, geom.D, wpp), dtype=torch.int64, device=dev)
@@ -158,10 +168,10 @@ class ProjectFused(torch.autograd.Function):
         geom = ctx.geom
         dev = pc32.device
         L = N.lib()
-        B, Npts = pc32.shape[0], pc32.shape[1]
-        P = geom.params(B, Npts)
+        B, Npts, reps = q32.shape[0], pc32.shape[1], _replicas(pc32, q32)
+        P = geom.params(B, Npts, reps)
         dproj32 = dproj.detach().to(torch.float32).contiguous()
-        dpc = torch.empty_like(pc32)
+        dpc = torch.zeros_like(pc32) if reps > 1 else torch.empty_like(pc32)  # replicas add into a shared gradient
         dsmall = torch.empty((N.DPC_SMALL_COLS * B,), dtype=torch.float32, device=dev)
         ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
         kxy, kz = geom.kern_ptrs()
@@ -192,7 +202,7 @@ class ProjectLossFused(torch.autograd.Function):
         dev = N.require_device(pc, q, t, f, s, gt)
         L = N.lib()
         pc32, q32, t32, f32, s32, gt32 = _f32(pc), _f32(q), _f32(t), _f32(f), _f32(s), _f32(gt)
-        B, Npts = pc32.shape[0], pc32.shape[1]
+        B, Npts, reps = q32.shape[0], pc32.shape[1], _replicas(pc32, q32)
         K = int(num_candidates)
         if K < 1 or B % K:
             raise ValueError("%d clouds is not a multiple of %d pose candidates" % (B, K))
@@ -200,7 +210,7 @@ class ProjectLossFused(torch.autograd.Function):
         if gt32.shape[0] != S or gt32[0].numel() != geom.H * geom.W:
             raise ValueError("gt must be [%d,%d,%d,1] (masks pooled to the silhouette size), got %s"
                              % (S, geom.H, geom.W, tuple(gt32.shape)))
-        P = geom.params(B, Npts)
+        P = geom.params(B, Npts, reps)
         wpp = L.dpc_mask_words_per_plane(ctypes.byref(P))
         f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         grid_wh, proj, trans = f32e(B, geom.D, geom.H, geom.W), f32e(B, geom.H, geom.W, 1), f32e(B, geom.H, geom.W)
@@ -241,10 +251,10 @@ class ProjectLossFused(torch.autograd.Function):
         has_t, has_f, has_s = ctx.has
         t32, f32, s32 = (t32 if has_t else None), (f32 if has_f else None), (s32 if has_s else None)
         geom, dev, L = ctx.geom, pc32.device, N.lib()
-        B, Npts = pc32.shape[0], pc32.shape[1]
-        P = geom.params(B, Npts)
+        B, Npts, reps = q32.shape[0], pc32.shape[1], _replicas(pc32, q32)
+        P = geom.params(B, Npts, reps)
         dl = dloss.detach().to(torch.float32).reshape(())
-        dpc = torch.empty_like(pc32)
+        dpc = torch.zeros_like(pc32) if reps > 1 else torch.empty_like(pc32)  # replicas add into a shared gradient
         if ctx.fused:
             if not ctx.fresh:  # a second backward through the same node: the gather's accumulators must start at zero
                 dsmall[:4 * B].zero_()

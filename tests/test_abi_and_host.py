@@ -45,16 +45,16 @@ def test_size_queries_and_validation_without_gpu():
     from dpc.render import _native
 
     L = _native.lib()
-    P = _native.DpcParams(32, 8000, 64, 64, 64, 21, 21, 2.0, 1.875, 1e-5, 10.0)
+    P = _native.DpcParams(32, 8000, 64, 64, 64, 21, 21, 2.0, 1.875, 1e-5, 10.0, 1)
     assert L.dpc_mask_words_per_plane(ctypes.byref(P)) == 64
     assert L.dpc_cells_bytes(ctypes.byref(P)) == 32 * 32 * (256 * 32 + 144)
     ws = L.dpc_workspace_bytes(ctypes.byref(P))
     assert ws >= 32 * 64 ** 3 * 4 and ws % 256 == 0
-    bad = _native.DpcParams(1, 10, 2048, 64, 64, 0, 0, 2.0, 1.875, 1e-5, 10.0)  # D beyond the 10-bit cell index
+    bad = _native.DpcParams(1, 10, 2048, 64, 64, 0, 0, 2.0, 1.875, 1e-5, 10.0, 1)  # D beyond the 10-bit cell index
     assert L.dpc_workspace_bytes(ctypes.byref(bad)) == 0
     # argument validation happens before any launch: NULL pointers / even tap counts are refused on CPU too
     assert L.dpc_project_fwd(ctypes.byref(P), *([None] * 16)) == -1  # 16 pointer arguments
-    even = _native.DpcParams(1, 10, 16, 16, 16, 4, 4, 2.0, 1.875, 1e-5, 10.0)
+    even = _native.DpcParams(1, 10, 16, 16, 16, 4, 4, 2.0, 1.875, 1e-5, 10.0, 1)
     assert L.dpc_transform_fwd(ctypes.byref(even), *([None] * 6)) == -3
 
 

@@ -453,6 +453,47 @@ def test_project_loss_fused_shapes(R, O, B, N, G, ksz, sig):
         close(gs.grad, cs.grad, 3e-5, "fused K=1 ds")
 
 
+@pytest.mark.parametrize("K,reps,sig", [(1, 4, 0.64), (4, 8, 1.1), (2, 2, 0.64), (1, 2, 1.1)])
+def test_shared_point_sets(R, O, K, reps, sig):
+    """[B/R,N,3] point sets shared by R consecutive clouds (views x pose candidates of one object)
+    give the very same silhouettes, loss and winners as the materialised tf_repeat_0 copy, and a point gradient that is
+    the sum over the replicas.  Both entry points (with and without the fused loss)."""
+    S_obj, N, G = 3, 1100, 32
+    B = S_obj * reps
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    kern = R.smoothing_kernel(cfg, sig)  # 0.64: specialised slab kernels; 1.1 (radius 6 at G=32): the generic ones
+    pc, _, _, _, _, _ = O.synth_inputs(S_obj, N, G, 61)
+    _, q, s, _, _, _ = O.synth_inputs(B, 4, G, 62)
+    gt = O.synth_inputs(B // K, 1, G, 63)[3]
+    full = pc.repeat_interleave(reps, dim=0)
+    a_pc, a_q, a_s = dev(full, True), dev(q, True), dev(s, True)
+    b_pc, b_q, b_s = dev(pc, True), dev(q, True), dev(s, True)
+    la, oa, wa = R.pointcloud_project_loss(cfg, a_pc, a_q, None, None, kern, scaling_factor=a_s, gt=dev(gt), num_candidates=K)
+    lb, ob, wb = R.pointcloud_project_loss(cfg, b_pc, b_q, None, None, kern, scaling_factor=b_s, gt=dev(gt), num_candidates=K)
+    (1.7 * la).backward()
+    (1.7 * lb).backward()
+    # (not bit for bit: the generic slab kernels accumulate the splat with fp32 LDS atomics, whose order varies run to run)
+    close(ob["proj"], oa["proj"], 1e-6, "shared points: proj")
+    close(lb, la, 1e-6, "shared points: loss")
+    assert torch.equal(wa, wb)
+    assert b_pc.grad.shape == (S_obj, N, 3)
+    close(b_pc.grad, a_pc.grad.reshape(S_obj, reps, N, 3).sum(1), 2e-6, "shared points: dpc summed over replicas (K=%d)" % K)
+    close(b_q.grad, a_q.grad, 1e-6, "shared points: dq")
+    close(b_s.grad, a_s.grad, 1e-6, "shared points: ds")
+    close(ob["voxels"], oa["voxels"], 1e-7, "shared points: lazy voxels")
+    # the plain entry point, external loss
+    a_pc.grad = b_pc.grad = None
+    pa = R.pointcloud_project_fast(cfg, a_pc, a_q, None, None, kern, scaling_factor=a_s)["proj"]
+    pb = R.pointcloud_project_fast(cfg, b_pc, b_q, None, None, kern, scaling_factor=b_s)["proj"]
+    w = dev(torch.rand(pa.shape, generator=torch.Generator().manual_seed(3)))
+    (pa * w).sum().backward()
+    (pb * w).sum().backward()
+    close(pb, pa, 1e-6, "shared points: proj (plain entry point)")
+    close(b_pc.grad, a_pc.grad.reshape(S_obj, reps, N, 3).sum(1), 2e-6, "shared points: dpc (plain entry point)")
+    with pytest.raises(ValueError):
+        R.pointcloud_project_fast(cfg, dev(pc[:2]), dev(q[:3]), None, None, kern)
+
+
 def test_config4_full_size(R, O):
     """BASELINE config 4 per-GPU shard: 8 clouds x 16000 pts -> 128^3, sigma = 0.01 (sigma_rel 1.28), 21 taps.
     Size-independent properties on all 8 clouds + the oracle on one of them (128^3 fp64 on CPU takes seconds)."""
