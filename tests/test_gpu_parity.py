@@ -453,15 +453,16 @@ def test_project_loss_fused_shapes(R, O, B, N, G, ksz, sig):
         close(gs.grad, cs.grad, 3e-5, "fused K=1 ds")
 
 
-@pytest.mark.parametrize("K,reps,sig", [(1, 4, 0.64), (4, 8, 1.1), (2, 2, 0.64), (1, 2, 1.1)])
-def test_shared_point_sets(R, O, K, reps, sig):
+@pytest.mark.parametrize("K,reps,sig,G", [(1, 4, 0.64, 32), (4, 8, 1.1, 32), (2, 2, 0.64, 32), (1, 2, 1.1, 32), (2, 4, 0.8, 24),
+                                            (1, 3, 0.64, 64)])
+def test_shared_point_sets(R, O, K, reps, sig, G):
     """[B/R,N,3] point sets shared by R consecutive clouds (views x pose candidates of one object)
     give the very same silhouettes, loss and winners as the materialised tf_repeat_0 copy, and a point gradient that is
     the sum over the replicas.  Both entry points (with and without the fused loss)."""
-    S_obj, N, G = 3, 1100, 32
+    S_obj, N = 3, 1100
     B = S_obj * reps
     cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
-    kern = R.smoothing_kernel(cfg, sig)  # 0.64: specialised slab kernels; 1.1 (radius 6 at G=32): the generic ones
+    kern = R.smoothing_kernel(cfg, sig)  # G = 24: the generic (runtime-dimension) kernels; 32 and 64: the specialised ones
     pc, _, _, _, _, _ = O.synth_inputs(S_obj, N, G, 61)
     _, q, s, _, _, _ = O.synth_inputs(B, 4, G, 62)
     gt = O.synth_inputs(B // K, 1, G, 63)[3]
