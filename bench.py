@@ -348,7 +348,7 @@ def main():
         "loss_mean": float(loss_t.item() / world),
     }
     out.update(extras)
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # the CPU leg is a single-GPU-run item (rank 0 at N=1 only)
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
     if world > 1:
