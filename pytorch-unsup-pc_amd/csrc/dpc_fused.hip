@@ -650,10 +650,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
           for (int e = 0; e < 2; ++e) {
             const int idx = 2 * k + e;
             if (idx >= Geo::PAD && idx < Geo::PAD + Geo::LW) bits |= (a2[e] <= kFixOne ? 1u : 0u) << (idx - Geo::PAD);
-            const float fv = to_float(a2[e]);
-            if (raw != nullptr && idx >= Geo::PAD && idx < Geo::PAD + Geo::LW && row / GS < nz)  // optional output: the unclamped splat
-              raw[((size_t)b * D + z0) * HW + (size_t)row * GS + seg * Geo::LW + (idx - Geo::PAD)] = fv;
-            v[idx] = fminf(fv, 1.0f);
+            v[idx] = fminf(to_float(a2[e]), 1.0f);
           }
         }
       }
@@ -1626,7 +1623,10 @@ int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const T
 template <int RB>
 int launch_splat(const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
                  uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st) {
-  if (p->H == p->W) {
+  // The specialised kernel's W-pass branch does not produce the optional unclamped grid (`raw`, asked for by direct
+  // users of dpc_project_fwd only): that request takes the generic kernel, which keeps the hot loop free of it.
+  const bool raw_with_passes = raw != nullptr && Tbuf != nullptr && RB > 0;
+  if (p->H == p->W && !raw_with_passes) {
     if constexpr (RB <= 4) {
       if (p->H == 32) return launch_splat_fast<32, 4, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
       if (p->H == 128) return launch_splat_fast<128, 1, RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
