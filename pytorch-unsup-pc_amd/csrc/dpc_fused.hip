@@ -52,6 +52,7 @@ namespace {
 
 constexpr int kSlabThreads = 1024;
 constexpr int kColThreads = 256;
+constexpr int kNumCUs = 256;  // MI355X
 // k_zcol_fwdbwd's per-cloud word: [63:51] blocks arrived, [50:0] squared error, 30 fractional bits (a cloud's sum is
 // at most H*W <= 2^20)
 constexpr int kSseCountShift = 51, kSseFrac = 30;
@@ -1264,7 +1265,11 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   extern __shared__ __attribute__((aligned(16))) float slab[];
   const int D = P.D, H = P.H, W = P.W, N = P.N, HW = H * W;
   const int Zs = GS ? ZS : zs_rt;
-  const int b = blockIdx.y, z0 = blockIdx.x * Zs;
+  // One-layer slabs (planes too big for more: 128^2) ROLL: the workgroup walks `roll` consecutive layers, keeps the plane
+  // two layers share in LDS (ping-pong of the two plane buffers) and pays start-up, reduction and atomics once.
+  constexpr bool kRolls = GS > 0 && ZS == 1 && RB > 0;
+  const int roll = kRolls ? zs_rt : 1;
+  const int b = blockIdx.y, z0 = blockIdx.x * Zs * roll;
   const int reps = P.point_replicas > 1 ? P.point_replicas : 1;
   const bool shared_points = reps > 1;  // dpc is [B/reps,N,3], zeroed by the caller; replicas add into it
   if (cloud_loses(la, b)) {  // a losing pose candidate: zero gradient, no work (block-uniform)
@@ -1277,7 +1282,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
       const int i = aux->w;
       dz[3 * i + 0] = 0.f; dz[3 * i + 1] = 0.f; dz[3 * i + 2] = 0.f;
     };
-    for_each_record(cells, b, z0, min(z0 + Zs, D), zero3);
+    for_each_record(cells, b, z0, min(z0 + Zs * roll, D), zero3);
     if (blockIdx.x == 0) {
       for_each_record(cells, b, D, D + 1, zero3);
       if (threadIdx.x == 0) dsmall[(size_t)DPC_COL_DS * P.B + b] = 0.f;
@@ -1404,7 +1409,8 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
         for (int j = 0; j < 2; ++j) {
           cv[k][j][0] = cv[k][j][1] = 0.f;
           if ((c.iz + k < D) && (c.iy + j < GS)) {
-            const int row = (c.iz - z0 + k) * GS + c.iy + j;
+            const int plane = kRolls ? ((c.iz - z0 + k) & 1) : (c.iz - z0 + k);  // rolling: plane z lives in buffer (z - z0) & 1
+            const int row = plane * GS + c.iy + j;
             const float* rp = slab + row * Geo::WP + Geo::PAD + c.ix - RB;  // x = ix-RB .. ix+1+RB, pads are zero
             float v[2 * RB + 2];
 #pragma unroll
@@ -1454,6 +1460,39 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   if (!DPC_ABL(10)) {
     if (GS > 0 && cells.nblk <= DPC_WAVE) for_each_record_flat(cells, b, reinterpret_cast<const int*>(red + kRedTab), gather);
     else for_each_record(cells, b, z0, min(z0 + Zs, D), gather);
+  }
+  if constexpr (kRolls) {
+    using Geo = BwdGeo<GS, RB, 2>;
+    constexpr int MW1 = GS * (GS / 32), MPT1 = (MW1 + Geo::NT - 1) / Geo::NT;  // clamp-mask words of one plane
+    const uint32_t* mask32 = reinterpret_cast<const uint32_t*>(mrow);
+    uint32_t* mlds = reinterpret_cast<uint32_t*>(red + kRedMask);
+    int* tab = reinterpret_cast<int*>(red + kRedTab);
+    const bool flat = cells.nblk <= DPC_WAVE;
+    for (int l = 1; l < roll && z0 + l < D; ++l) {
+      __syncthreads();  // layer l-1 is gathered: plane z0+l-1 (buffer (l-1)&1 == (l+1)&1) and the record table are free
+      const int buf = (l + 1) & 1;
+      const bool present = z0 + l + 1 < D;
+      RecordRange rr{0, 0};
+      if (flat) rr = load_record_range(cells, b, z0 + l, z0 + l + 1);
+      uint32_t mreg[MPT1];
+#pragma unroll
+      for (int it = 0; it < MPT1; ++it) {
+        const int w = tid + it * Geo::NT;
+        mreg[it] = (w < MW1 && present) ? mask32[(size_t)(l + 1) * MW1 + w] : 0u;
+      }
+      hpass_global<Geo, GS, RB, 1>(src + (size_t)(l + 1) * HW, present ? 1 : 0, taps_adj, [&](int, int y, int x, f32x2 val) {
+        *reinterpret_cast<f32x2*>(slab + Geo::at(buf, y, x)) = val;
+      });
+#pragma unroll
+      for (int it = 0; it < MPT1; ++it) {
+        const int w = tid + it * Geo::NT;
+        if (w < MW1) mlds[buf * MW1 + w] = mreg[it];
+      }
+      if (flat) finish_record_table(rr, tab);
+      __syncthreads();
+      if (flat) for_each_record_flat(cells, b, tab, gather);
+      else for_each_record(cells, b, z0 + l, z0 + l + 1, gather);
+    }
   }
   DPC_STAMP(11);
   if (blockIdx.x == 0 && !shared_points)
@@ -1663,8 +1702,14 @@ int launch_gather_fast(const DpcParams* p, Cells cells, const float* pc, const f
   auto kern = k_gather_hw<GS, ZS, RB>;
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
-  DPC_LAUNCH("k_gather_hw", kern, dim3((p->D + ZS - 1) / ZS, p->B), dim3(Geo::NT), lds, st, *p, cells, pc, q, t, f,
-             make_taps<RB>(kxy, pxy, true), ZS, dT, mask, ds_part, ntile, dpc, dsmall, la);
+  // one-layer slabs roll over several layers per workgroup (see the kernel): as many as still leave a workgroup per CU
+  int roll = 1;
+  if (ZS == 1 && RB > 0)
+    for (int c = 2; c <= 16; c *= 2)
+      if (p->D % c == 0 && (size_t)(p->D / c) * p->B >= (size_t)kNumCUs) roll = c;
+  const int nslab = (p->D + ZS - 1) / ZS;
+  DPC_LAUNCH("k_gather_hw", kern, dim3((nslab + roll - 1) / roll, p->B), dim3(Geo::NT), lds, st, *p, cells, pc, q, t, f,
+             make_taps<RB>(kxy, pxy, true), ZS == 1 ? roll : ZS, dT, mask, ds_part, ntile, dpc, dsmall, la);
   return launch_ok();
 }
 
