@@ -1,0 +1,615 @@
+// Shared by the kernel files of libdpc_render.so: layouts, LDS pass helpers, host-side launch plumbing.
+//   dpc_slab_fwd.hip   k_locate, k_splat_hw            (transform + cell location, splat + W/H passes)
+//   dpc_column.hip     k_zcol_fwd / _bwd / _fwdbwd     (D pass, DRC ray march and its backward, loss finalize)
+//   dpc_slab_bwd.hip   k_gather_hw                     (adjoint H/W passes, 8-corner gather, transform backward)
+//   dpc_entry.hip      C ABI of the fused path
+#pragma once
+#include <math.h>
+#include <string.h>
+
+#include "dpc_common.h"
+#include "dpc_profile.h"
+
+#ifdef DPC_ABLATE
+// Diagnostic builds only (-DDPC_ABLATE): per-translation-unit switches that cut work out of the kernels (timing
+// experiments; results are then wrong) and per-phase timestamps.  Every kernel file instantiates its own setters with
+// DPC_DEBUG_SETTERS(tag); dpc_entry.hip's dpc_debug_set_ablate / dpc_debug_set_stamps forward to all of them.
+static __device__ int g_dpc_ablate = 0;
+#define DPC_ABL(bit) (g_dpc_ablate & (1 << (bit)))
+// 100 MHz s_memrealtime (comparable across CUs), thread 0 of every workgroup; 16 slots per block
+static __device__ unsigned long long* g_dpc_stamps = nullptr;
+#define DPC_STAMP(slot)                                                                                    \
+  do {                                                                                                     \
+    if (g_dpc_stamps != nullptr && threadIdx.x == 0)                                                       \
+      g_dpc_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+#define DPC_DEBUG_SETTERS(tag)                                                                                          \
+  extern "C" int dpc_debug_set_ablate_##tag(int v) {                                                                    \
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_dpc_ablate), &v, sizeof(int)) == hipSuccess ? 0 : -5;                         \
+  }                                                                                                                     \
+  extern "C" int dpc_debug_set_stamps_##tag(void* p) {                                                                  \
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_dpc_stamps), &p, sizeof(void*)) == hipSuccess ? 0 : -5;                       \
+  }
+#else
+#define DPC_ABL(bit) 0
+#define DPC_STAMP(slot) do { } while (0)
+#define DPC_DEBUG_SETTERS(tag)
+#endif
+
+namespace dpck {
+
+constexpr int kSlabThreads = 1024;
+constexpr int kColThreads = 256;
+constexpr int kNumCUs = 256;  // MI355X
+// k_zcol_fwdbwd's per-cloud word: [63:51] blocks arrived, [50:0] squared error, 30 fractional bits (a cloud's sum is
+// at most H*W <= 2^20)
+constexpr int kSseCountShift = 51, kSseFrac = 30;
+#ifndef DPC_ZFB_RPL
+#define DPC_ZFB_RPL 1  // rays per lane in k_zcol_fwdbwd (1 or 2)
+#endif
+constexpr int kLocThreads = 256;                     // points per locate block == points per sorted chunk
+constexpr int kL = 16;                               // outputs per thread in the generic in-LDS line convolutions
+constexpr int kLdsLimit = 160 * 1024;                // bytes of LDS a workgroup may use on gfx950
+constexpr int kRedTab = 256;     // float offset of the record table inside the backward kernel's scratch tail
+constexpr int kRedMask = 400;    // float offset of the staged clamp-mask words
+constexpr int kRedFloats = 1024; // generic kernels: reduction scratch (13 x 16 floats) + record table
+constexpr int kLdsBudget = kLdsLimit - 4096;         // generic slab bytes; the rest holds the reduction scratch
+
+__device__ inline int odd_stride(int w) { return w | 1; }  // generic LDS row stride: odd => conflict-free column walks
+
+// ------------------------------------------------------------------------------------------------------
+// Binned point storage ("cells"): per cloud, ceil(N/256) chunks; chunk c holds the records of points
+// [256c, 256c+256) counting-sorted by bin (bin = z cell iz, or D for out-of-bounds points):
+//   [256 x PointRec (16 B)] [256 x {px, py, pz, original index} (16 B)] [(D+2) x uint16 bin start offsets, padded to 16 B]
+// offs[k] = first sorted position of bin k; offs[D+1] = number of points in the chunk.
+// ------------------------------------------------------------------------------------------------------
+__host__ __device__ inline size_t chunk_bytes(int D) {
+  return (size_t)kLocThreads * 2 * sizeof(PointRec) + (((size_t)(D + 2) * 2 + 15) / 16) * 16;
+}
+__host__ __device__ inline int num_chunks(int N) { return (N + kLocThreads - 1) / kLocThreads; }
+
+struct Cells {
+  const uint8_t* base;
+  size_t chunk;   // bytes per chunk
+  int nblk;       // chunks per cloud
+  __device__ const uint8_t* at(int b, int blk) const { return base + ((size_t)b * nblk + blk) * chunk; }
+  __device__ const PointRec* recs(int b, int blk) const { return reinterpret_cast<const PointRec*>(at(b, blk)); }
+  // the point itself and its original index, sorted like the records (the backward reads them sequentially)
+  __device__ const int4* aux(int b, int blk) const {
+    return reinterpret_cast<const int4*>(at(b, blk) + (size_t)kLocThreads * sizeof(PointRec));
+  }
+  __device__ const uint16_t* offs(int b, int blk) const {
+    return reinterpret_cast<const uint16_t*>(at(b, blk) + (size_t)kLocThreads * 2 * sizeof(PointRec));
+  }
+};
+
+// Visit every record of cloud b whose bin lies in [bin_lo, bin_hi).  f(rec, aux) with aux -> {px,py,pz,orig}.
+//   build_record_table (wave 0, before a barrier the caller already has): lane c reads chunk c's range, an
+//   inclusive scan over lanes gives every chunk's first flat index; tab = {prefix[nblk+1], begin[nblk]} in LDS.
+//   for_each_record_flat: threads take flat indices tid, tid+nthr, ... and find their chunk by binary search in
+//   the table -- balanced over the whole workgroup and only two dependent global reads deep (offsets, record).
+// Needs nblk <= 64 (N <= 16384); larger clouds use the wave-per-chunk loop below.
+constexpr int kTabInts = 2 * DPC_WAVE + 2;
+
+struct RecordRange {  // wave 0, lane c: sorted range [beg, beg+cnt) of chunk c
+  int beg, cnt;
+};
+
+// Issue the offset loads early (they are only waited for in finish_record_table, so a whole phase can run under them).
+__device__ inline RecordRange load_record_range(const Cells& cells, int b, int bin_lo, int bin_hi) {
+  RecordRange r{0, 0};
+  const int c = threadIdx.x;
+  if (c < DPC_WAVE && c < cells.nblk) {
+    const uint16_t* offs = cells.offs(b, c);
+    r.beg = offs[bin_lo];
+    r.cnt = (int)offs[bin_hi] - r.beg;
+  }
+  return r;
+}
+
+__device__ inline void finish_record_table(const RecordRange& r, int* tab) {
+  if (threadIdx.x >= DPC_WAVE) return;
+  const int c = threadIdx.x;
+  int incl = r.cnt;
+#pragma unroll
+  for (int off = 1; off < DPC_WAVE; off <<= 1) {
+    const int up = __shfl_up(incl, off, DPC_WAVE);
+    if (c >= off) incl += up;
+  }
+  tab[c] = incl - r.cnt;               // exclusive prefix
+  tab[DPC_WAVE + 1 + c] = r.beg;
+  if (c == DPC_WAVE - 1) tab[DPC_WAVE] = incl;  // total
+}
+
+// flat index j -> (chunk, sorted position): largest c with tab[c] <= j (prefix non-decreasing; empty chunks repeat)
+__device__ inline void flat_lookup(const int* tab, int j, int& chunk, int& pos) {
+  int lo = 0, hi = DPC_WAVE;
+#pragma unroll
+  for (int step = 0; step < 6; ++step) {
+    const int mid = (lo + hi) >> 1;
+    if (tab[mid] <= j) lo = mid; else hi = mid;
+  }
+  chunk = lo;
+  pos = tab[DPC_WAVE + 1 + lo] + (j - tab[lo]);
+}
+
+template <class F>
+__device__ inline void for_each_record_flat(const Cells& cells, int b, const int* tab, F f, int first = 0) {
+  const int total = tab[DPC_WAVE];
+  for (int j = first + threadIdx.x; j < total; j += blockDim.x) {
+    int c, pos;
+    flat_lookup(tab, j, c, pos);
+    f(load_record(cells.recs(b, c), pos), cells.aux(b, c) + pos);
+  }
+}
+
+template <class F>
+__device__ inline void for_each_record(const Cells& cells, int b, int bin_lo, int bin_hi, F f) {
+  const int lane = threadIdx.x & (DPC_WAVE - 1), wave = threadIdx.x / DPC_WAVE, nw = blockDim.x / DPC_WAVE;
+  for (int blk = wave; blk < cells.nblk; blk += nw) {
+    const uint16_t* offs = cells.offs(b, blk);
+    const int beg = __builtin_amdgcn_readfirstlane((int)offs[bin_lo]);
+    const int end = __builtin_amdgcn_readfirstlane((int)offs[bin_hi]);
+    const PointRec* recs = cells.recs(b, blk);
+    const int4* aux = cells.aux(b, blk);
+    for (int j = beg + lane; j < end; j += DPC_WAVE) f(load_record(recs, j), aux + j);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Generic in-LDS separable passes over a slab laid out [nz][H][WP] (runtime dims, bounds-checked windows).
+// Every thread owns (line, segment-of-kL-outputs); all windows are read, then a barrier, then written back,
+// so the pass is in place.  Lanes map to consecutive lines (W-pass: stride WP odd; H-pass: consecutive x),
+// which keeps ds_read_b32/ds_write_b32 bank-conflict free.
+// ------------------------------------------------------------------------------------------------------
+template <int RB, bool CLAMP1, class Post>
+__device__ inline void wpass_inplace(float* slab, int nz, int H, int W, int WP, const TapsT<RB>& taps, Post post) {
+  const int nseg = (W + kL - 1) / kL;
+  const int lines = nz * H;
+  const int per_round = blockDim.x / nseg;
+  for (int l0 = 0; l0 < lines; l0 += per_round) {
+    const int li = threadIdx.x % per_round, seg = threadIdx.x / per_round;
+    const int line = l0 + li;
+    const bool act = seg < nseg && line < lines;
+    float v[kL + 2 * RB];
+    if (act) window_load<RB, kL, CLAMP1>(v, slab + line * WP, 1, seg * kL, W);
+    __syncthreads();
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < kL; ++j) {
+        const int x = seg * kL + j;
+        if (x < W) slab[line * WP + x] = post(line, x, window_dot<RB, kL>(v, taps, j));
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int RB, class Store>
+__device__ inline void hpass(float* slab, int nz, int H, int W, int WP, const TapsT<RB>& taps, Store store) {
+  const int nseg = (H + kL - 1) / kL;
+  const int lines = nz * W;
+  const int per_round = blockDim.x / nseg;
+  for (int l0 = 0; l0 < lines; l0 += per_round) {
+    const int li = threadIdx.x % per_round, seg = threadIdx.x / per_round;
+    const int line = l0 + li;
+    const bool act = seg < nseg && line < lines;
+    const int z = line / W, x = line - z * W;
+    float v[kL + 2 * RB];
+    if (act) window_load<RB, kL, false>(v, slab + z * H * WP + x, WP, seg * kL, H);
+    __syncthreads();
+    if (act) {
+#pragma unroll
+      for (int j = 0; j < kL; ++j) {
+        const int y = seg * kL + j;
+        if (y < H) store(z, y, x, window_dot<RB, kL>(v, taps, j));
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Specialised slab geometry: H = W = GS known at compile time.
+//   row layout   [PAD zeros][GS values], PAD = max(4, RB rounded up to 4): rows start 16-byte aligned, the
+//                zero pad of row r+1 doubles as the right halo of row r, so W-windows need no bounds checks
+//   W-pass       thread = (row, 32-output segment); lanes walk consecutive rows (stride GS+PAD floats keeps
+//                ds_read_b128 / ds_write_b128 conflict-free for PAD = 4)
+//   H-pass       thread = (plane, column PAIR, 16-output segment); ds_read_b64 of two adjacent columns and
+//                packed v_pk_fma_f32 on the pair
+// ------------------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int GS, int RB, int NT_, int LW_, int LH_>
+struct SlabGeo {
+  static constexpr int PAD = RB <= 4 ? 4 : ((RB + 3) / 4) * 4;
+  static constexpr int WP = GS + PAD;
+  // row stride of the forward's 64-bit accumulators (u64 units).  GS + PAD is a multiple of 4, i.e. 8 mod 16 dwords:
+  // lanes that walk rows with ds_read_b128 then use only every other group of four banks (2-way conflict in every
+  // 16-lane group; SQ_LDS_BANK_CONFLICT was half of SQ_LDS_IDX_ACTIVE).  Two spare (always zero) entries per row make
+  // the stride 4 or 12 mod 16 dwords: sixteen consecutive rows land on sixteen distinct bank groups.
+  static constexpr int WPA = GS + PAD + 2;
+  static constexpr int PLANE = GS * WP;
+  static constexpr int LW = LW_, NSEGW = GS / LW, LWIN = LW + 2 * PAD;              // W-pass
+  static constexpr int LH = LH_, NSEGH = GS / LH, XP = GS / 2, HWIN = LH + 2 * RB;  // H-pass
+  static constexpr int NT = NT_;
+  __host__ __device__ static constexpr size_t slab_floats(int planes) { return (size_t)planes * PLANE + PAD; }
+  __device__ static int at(int z, int y, int x) { return (z * GS + y) * WP + PAD + x; }
+};
+// forward: ZS planes, 16 voxels per thread, short segments so that every thread owns exactly one W and one H item
+template <int GS, int ZS, int RB>
+using FwdGeo = SlabGeo<GS, RB, ZS * GS * GS / 16, 16, 8>;
+// backward: NPL = ZS+1 planes (halo), long segments; one item per thread up to 1024 threads
+constexpr int bwd_threads(int gs, int npl) {
+  const int items = npl * gs * (gs / 32);
+  return items >= 1024 ? 1024 : (items <= 256 ? 256 : ((items + 63) / 64) * 64);
+}
+template <int GS, int RB, int NPL>
+using BwdGeo = SlabGeo<GS, RB, bwd_threads(GS, NPL), 32, 16>;
+
+constexpr float kFixScale = 17592186044416.0f;          // 2^44: splat weights accumulate as 64-bit fixed point
+constexpr float kFixInv = 1.0f / 17592186044416.0f;
+constexpr unsigned long long kFixOne = 1ull << 44;
+
+// In-place W-pass over NPL planes.  MASK: 0 none, 1 emit the clamp mask from the raw values (forward),
+// 2 multiply the outputs by the stored mask bits (backward).  mask32 points at this slab's first plane.
+template <class Geo, int GS, int NPL>
+__host__ __device__ constexpr int wpass_items_per_thread() {
+  return (NPL * GS * Geo::NSEGW + Geo::NT - 1) / Geo::NT;
+}
+
+// Request the clamp-mask words of this thread's W-pass items ahead of time (MASK = 3 below consumes them).
+template <class Geo, int GS, int NPL>
+__device__ inline void wpass_mask_prefetch(const uint32_t* __restrict__ mask32, int planes_present,
+                                           uint32_t (&bits)[wpass_items_per_thread<Geo, GS, NPL>()]) {
+  constexpr int ROWS = NPL * GS, ITEMS = ROWS * Geo::NSEGW, IPT = wpass_items_per_thread<Geo, GS, NPL>();
+#pragma unroll
+  for (int it = 0; it < IPT; ++it) {
+    const int item = threadIdx.x + it * Geo::NT;
+    bits[it] = 0u;
+    if (item < ITEMS) {
+      const int row = item % ROWS, seg = item / ROWS;
+      if (row / GS < planes_present) bits[it] = mask32[(size_t)row * Geo::NSEGW + seg];
+    }
+  }
+}
+
+template <class Geo, int GS, int RB, int NPL, bool CLAMP1, int MASK>
+__device__ inline void wpass_fast(float* slab, const TapsT<RB>& taps, const uint32_t* mask32, int planes_present) {
+  constexpr int ROWS = NPL * GS, ITEMS = ROWS * Geo::NSEGW, IPT = (ITEMS + Geo::NT - 1) / Geo::NT;
+  float v[IPT][Geo::LWIN];
+#pragma unroll
+  for (int it = 0; it < IPT; ++it) {
+    const int item = threadIdx.x + it * Geo::NT;
+    if (item < ITEMS) {
+      const int row = item % ROWS, seg = item / ROWS;
+      const f32x4* src = reinterpret_cast<const f32x4*>(slab + row * Geo::WP + seg * Geo::LW);
+#pragma unroll
+      for (int k = 0; k < Geo::LWIN / 4; ++k) {
+        const f32x4 q = src[k];
+        v[it][4 * k + 0] = q.x; v[it][4 * k + 1] = q.y; v[it][4 * k + 2] = q.z; v[it][4 * k + 3] = q.w;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < IPT; ++it) {
+    const int item = threadIdx.x + it * Geo::NT;
+    if (item < ITEMS) {
+      const int row = item % ROWS, seg = item / ROWS;
+      const int z = row / GS;
+      uint32_t bits = 0xffffffffu;
+      static_assert(MASK != 1, "the forward emits its mask from the fixed-point accumulators");
+      static_assert(MASK == 0 || Geo::LW == 32, "mask word addressing assumes 32-output segments");
+      if (MASK == 2) bits = z < planes_present ? mask32[(size_t)row * Geo::NSEGW + seg] : 0u;  // bits of the row's mask word
+      if (MASK == 3) bits = mask32[it];  // prefetched by wpass_mask_prefetch (registers)
+      if (CLAMP1) {
+#pragma unroll
+        for (int k = 0; k < Geo::LWIN; ++k) v[it][k] = fminf(v[it][k], 1.0f);
+      }
+      f32x4* dst = reinterpret_cast<f32x4*>(slab + row * Geo::WP + Geo::PAD + seg * Geo::LW);
+#pragma unroll
+      for (int k = 0; k < Geo::LW / 4; ++k) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int j = 4 * k + e;
+          float acc = 0.f;
+#pragma unroll
+          for (int tp = 0; tp < 2 * RB + 1; ++tp) acc = fmaf(taps.w[tp], v[it][j + tp + Geo::PAD - RB], acc);
+          o[e] = (MASK >= 2 && !((bits >> j) & 1u)) ? 0.f : acc;
+        }
+        f32x4 q;
+        q.x = o[0]; q.y = o[1]; q.z = o[2]; q.w = o[3];
+        dst[k] = q;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// H-pass over NPL planes, two adjacent columns per thread.  store(z, y, x_even, pair) consumes the results;
+// INPLACE inserts the barrier between the window reads and the stores.
+template <class Geo, int GS, int RB, int NPL, bool INPLACE, class Store>
+__device__ inline void hpass_fast(const float* slab, const TapsT<RB>& taps, Store store) {
+  constexpr int ITEMS = NPL * Geo::XP * Geo::NSEGH, IPT = (ITEMS + Geo::NT - 1) / Geo::NT;
+  f32x2 v[IPT][Geo::HWIN];
+#pragma unroll
+  for (int it = 0; it < IPT; ++it) {
+    const int item = threadIdx.x + it * Geo::NT;
+    if (item < ITEMS) {
+      const int xp = item % Geo::XP, rest = item / Geo::XP;
+      const int z = rest % NPL, seg = rest / NPL;
+      const float* col = slab + Geo::at(z, 0, 2 * xp);
+      const int y0 = seg * Geo::LH - RB;
+#pragma unroll
+      for (int i = 0; i < Geo::HWIN; ++i) {
+        // only the first/last RB rows of a window can fall outside the plane (zero padding): clamp the
+        // address, then zero the value
+        const bool out = (i < RB && y0 + i < 0) || (i >= Geo::LH + RB && y0 + i >= GS);
+        const int y = out ? 0 : y0 + i;
+        f32x2 q = *reinterpret_cast<const f32x2*>(col + y * Geo::WP);
+        if (out) q = f32x2{0.f, 0.f};
+        v[it][i] = q;
+      }
+    }
+  }
+  if (INPLACE) __syncthreads();
+#pragma unroll
+  for (int it = 0; it < IPT; ++it) {
+    const int item = threadIdx.x + it * Geo::NT;
+    if (item < ITEMS) {
+      const int xp = item % Geo::XP, rest = item / Geo::XP;
+      const int z = rest % NPL, seg = rest / NPL;
+#pragma unroll
+      for (int j = 0; j < Geo::LH; ++j) {
+        f32x2 acc = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int tp = 0; tp < 2 * RB + 1; ++tp)
+          acc = __builtin_elementwise_fma(f32x2{taps.w[tp], taps.w[tp]}, v[it][j + tp], acc);
+        store(z, seg * Geo::LH + j, 2 * xp, acc);
+      }
+    }
+  }
+  if (INPLACE) __syncthreads();
+}
+
+// The same H-pass with the input planes in GLOBAL memory ([planes][GS][GS], dense): used by the backward slab
+// kernel so that dT is read once, convolved in registers and written to LDS once.  Planes >= planes_present and rows
+// outside the plane read as zero.
+template <class Geo, int GS, int RB, int NPL, class Store>
+__device__ inline void hpass_global(const float* __restrict__ src, int planes_present, const TapsT<RB>& taps, Store store) {
+  constexpr int ITEMS = NPL * Geo::XP * Geo::NSEGH, IPT = (ITEMS + Geo::NT - 1) / Geo::NT;
+#pragma unroll
+  for (int it = 0; it < IPT; ++it) {
+    const int item = threadIdx.x + it * Geo::NT;
+    if (item < ITEMS) {
+      const int xp = item % Geo::XP, rest = item / Geo::XP;
+      const int z = rest % NPL, seg = rest / NPL;
+      const float* col = src + (size_t)z * GS * GS + 2 * xp;
+      const int y0 = seg * Geo::LH - RB;
+      const bool have = z < planes_present;
+      f32x2 v[Geo::HWIN];
+#pragma unroll
+      for (int i = 0; i < Geo::HWIN; ++i) {
+        const int y = y0 + i;
+        const bool in = have && !((i < RB && y < 0) || (i >= Geo::LH + RB && y >= GS));
+        v[i] = in ? *reinterpret_cast<const f32x2*>(col + (size_t)y * GS) : f32x2{0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < Geo::LH; ++j) {
+        f32x2 acc = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int tp = 0; tp < 2 * RB + 1; ++tp)
+          acc = __builtin_elementwise_fma(f32x2{taps.w[tp], taps.w[tp]}, v[j + tp], acc);
+        store(z, seg * Geo::LH + j, 2 * xp, acc);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Shared per-voxel DRC pieces (dpc/util/drc.py:48-129)
+// ------------------------------------------------------------------------------------------------------
+struct RayConst {
+  float eps, hi;  // clamp bounds eps, 1-eps
+  float em1;      // e^eps - 1: the reference's "log-unity" rows are eps, not 0
+  float s;        // occupancy scale of this cloud
+  bool has_s;
+};
+
+// eps-derived constants are computed on the host in fp64 and travel as kernel arguments
+struct RayHost {
+  float eps, hi, em1;
+};
+
+__device__ inline RayConst ray_const(const RayHost& h, const float* s, int b) {
+  RayConst r;
+  r.eps = h.eps;
+  r.hi = h.hi;
+  r.em1 = h.em1;
+  r.has_s = s != nullptr;
+  r.s = r.has_s ? s[b] : 1.0f;
+  return r;
+}
+
+__device__ inline float occupancy(const RayConst& r, float v2) {  // scale + clamp (point_cloud_to.py:218-222)
+  return r.has_s ? fminf(fmaxf(r.s * v2, 0.f), 1.f) : v2;
+}
+
+__device__ inline float drc_clamp(const RayConst& r, float v3) { return fminf(fmaxf(v3, r.eps), r.hi); }
+
+// d proj / d v2 for one voxel given the ray's total transmittance; also returns v2 * dL/dv3 * mask for ds.
+// Branch-free and short (this loop is not hidden behind memory): 1/(1-y) via v_rcp_f32 (1 ulp; 1-y >= eps);
+//   inside = (eps <= v3 <= 1-eps)  <=>  the DRC clamp left v3 unchanged  <=>  y == v3;
+//   the scale clamp's pass-through set (0 <= s v2 <= 1) is implied by `inside` (v3 in [eps,1-eps] means the first
+//   clamp did not act either), so one select serves both masks.
+__device__ inline float drc_voxel_bwd(const RayConst& r, float v2, float g, float Tf, bool first, float& ds_term) {
+  const float v3 = occupancy(r, v2);
+  const float y = drc_clamp(r, v3);
+  float dv3 = g * fmaf(Tf, __builtin_amdgcn_rcpf(1.0f - y), first ? r.em1 : 0.f);
+  dv3 = (y == v3) ? dv3 : 0.f;
+  if (!r.has_s) {
+    ds_term = 0.f;
+    return dv3;
+  }
+  ds_term = v2 * dv3;
+  return r.s * dv3;
+}
+
+// Fused silhouette loss (dpc/models/model_pc_to.py:339-385, 410-440): cloud b is candidate b % K of sample b / K.
+//   forward : sse[b] += sum_pixels (gt - proj)^2            (k_zcol_fwd epilogue; zeroed by k_splat_hw)
+//   finalize: winner[s] = argmin_k sse[s*K+k], loss = sum_s min_k sse / S      (k_loss_finalize)
+//   backward: dproj = winner ? 2 (proj - gt) / S * dloss : 0, formed on the fly; losing candidates do nothing
+struct LossArgs {
+  const float* gt;      // [S, H*W] in image orientation (rows already flipped like proj); nullptr = no fused loss
+  float* sse;           // [B]
+  const int* winner;    // [S] (backward)
+  const float* dloss;   // device scalar, gradient arriving at the loss (backward); nullptr = 1
+  int K;
+  float inv_S;
+  float* loss_direct;   // forward, K == 1 only: the scalar loss, accumulated by the ray-march blocks (no finalize launch)
+  int* winner_out;      // forward, K == 1 only: zero-filled by k_splat_hw
+  int scale_in_gather;  // backward: dT was produced by the forward for dloss = 1; k_gather_hw multiplies by *dloss
+};
+
+// ------------------------------------------------------------------------------------------------------
+// Host side
+// ------------------------------------------------------------------------------------------------------
+struct TapPlan {
+  int taps;    // original length
+  int radius;  // effective radius after dropping negligible outer taps
+  int bucket;  // compile-time radius bucket, -1 = needs the generic column kernel / staged path
+};
+
+// Outer taps whose total |weight| is below 1e-8 of the kernel's mass change no fp32 result at the 1e-5
+// parity tolerance (inputs are clamped to [0,1], so each pass errs by < 1e-8); for sigma_rel = 0.64 this
+// keeps 7 of 21 taps (the dropped +-4 taps weigh 2e-9 each).
+inline TapPlan plan_taps(const float* k, int taps) {
+  TapPlan p{taps, 0, 0};
+  if (taps <= 0) return p;
+  const int c = (taps - 1) / 2;
+  double total = 0.0;
+  for (int i = 0; i < taps; ++i) total += fabs((double)k[i]);
+  int r = c;
+  double dropped = 0.0;
+  while (r > 0) {
+    const double d = fabs((double)k[c - r]) + fabs((double)k[c + r]);
+    if (dropped + d > 1e-8 * total) break;
+    dropped += d;
+    --r;
+  }
+  p.radius = r;
+  static const int buckets[] = {0, 1, 2, 3, 4, 6, 10, 15};
+  p.bucket = -1;
+  for (int bk : buckets)
+    if (r <= bk) {
+      p.bucket = bk;
+      break;
+    }
+  return p;
+}
+
+template <int RB>
+TapsT<RB> make_taps(const float* k, const TapPlan& p, bool flip) {
+  TapsT<RB> t;
+  for (int i = 0; i < 2 * RB + 1; ++i) t.w[i] = 0.f;
+  if (p.taps > 0) {
+    const int c = (p.taps - 1) / 2;
+    for (int o = -p.radius; o <= p.radius; ++o) t.w[RB + o] = k[c + (flip ? -o : o)];
+  } else {
+    t.w[RB] = 1.f;
+  }
+  return t;
+}
+
+inline TapsDyn make_taps_dyn(const float* k, int taps, bool flip) {
+  TapsDyn t;
+  t.n = taps;
+  for (int i = 0; i < DPC_MAX_TAPS; ++i) t.w[i] = 0.f;
+  for (int i = 0; i < taps; ++i) t.w[i] = k[flip ? taps - 1 - i : i];
+  return t;
+}
+
+inline int validate(const DpcParams* p) {
+  if (p == nullptr) return DPC_ERR_NULL;
+  if (p->B < 0 || p->N < 0 || p->D < 1 || p->H < 1 || p->W < 1) return DPC_ERR_SHAPE;
+  if (p->D > 1024 || p->H > 1024 || p->W > 1024 || p->B > 65535) return DPC_ERR_SHAPE;  // 10-bit cell indices
+  if (p->point_replicas < 0 || (p->point_replicas > 1 && p->B % p->point_replicas != 0)) return DPC_ERR_SHAPE;
+  for (int taps : {p->taps_xy, p->taps_z})
+    if (taps < 0 || taps > DPC_MAX_TAPS || (taps > 0 && taps % 2 == 0)) return DPC_ERR_TAPS;
+  return DPC_OK;
+}
+
+// planes of an H x W slab that fit the LDS tile of the generic kernels
+inline int planes_fit(const DpcParams* p) { return kLdsBudget / ((p->H * (p->W | 1)) * (int)sizeof(float)); }
+inline int slab_threads(const DpcParams* p) { return (long long)p->H * p->W >= 2048 ? kSlabThreads : 256; }
+inline int col_tiles(const DpcParams* p) { return (p->H * p->W + kColThreads - 1) / kColThreads; }
+
+template <class K>
+int set_lds(K kernel, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)bytes) == hipSuccess
+             ? DPC_OK
+             : DPC_ERR_LAUNCH;
+}
+
+inline RayHost ray_host(const DpcParams* p) {
+  const double eps = (double)p->clip_val;
+  return RayHost{p->clip_val, (float)(1.0 - eps), (float)expm1(eps)};
+}
+
+inline int launch_ok() { return hipGetLastError() == hipSuccess ? DPC_OK : DPC_ERR_LAUNCH; }
+
+inline Cells cells_view(const DpcParams* p, const void* cells) {
+  return Cells{static_cast<const uint8_t*>(cells), chunk_bytes(p->D), num_chunks(p->N)};
+}
+
+#define DPC_FOR_BUCKET(bucket, MACRO) \
+  switch (bucket) {                   \
+    case 0: MACRO(0); break;          \
+    case 1: MACRO(1); break;          \
+    case 2: MACRO(2); break;          \
+    case 3: MACRO(3); break;          \
+    case 4: MACRO(4); break;          \
+    case 6: MACRO(6); break;          \
+    case 10: MACRO(10); break;        \
+    case 15: MACRO(15); break;        \
+    default: rc = DPC_ERR_TAPS;       \
+  }
+
+#ifndef DPC_FWD_ZS64
+#define DPC_FWD_ZS64 4
+#endif
+constexpr int kFwdZs64 = DPC_FWD_ZS64;
+#ifndef DPC_BWD_ZS64
+#define DPC_BWD_ZS64 8
+#endif
+constexpr int kBwdZs64 = DPC_BWD_ZS64;  // cell layers per backward slab at G = 64 (8 -> 9 planes, 1 workgroup/CU; 3 -> 4 planes, 2/CU)  // planes per forward slab at G = 64 (4 -> 1 workgroup/CU, 2 -> 2 workgroups/CU)
+
+
+// losing pose candidates of the fused min-of-K loss do no backward work
+__device__ inline bool cloud_loses(const LossArgs& la, int b) {
+  return la.gt != nullptr && la.winner[b / la.K] != b % la.K;
+}
+
+// ---- launchers defined next to their kernels (bucket = compile-time tap radius bucket chosen by plan_taps) ----
+int launch_locate(const DpcParams* p, int src, const void* pts, const float* q, const float* t, const float* f, float* tr_pc,
+                  void* cells, hipStream_t st);
+int launch_splat(int bucket, const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
+                 uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st);
+int launch_gather(int bucket, const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
+                  const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part, int ntile,
+                  float* dpc, float* dsmall, const LossArgs& la, hipStream_t st);
+int launch_zcol_fwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* Tbuf, const float* s,
+                    float* smoothed, float* proj, float* trans, const LossArgs& la, hipStream_t st);
+int launch_zcol_fwdbwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* Tbuf, const float* s,
+                       float* proj, float* dT, float* ds_part, int ntile, unsigned long long* tickets, float* bwd_dsmall,
+                       const LossArgs& la, hipStream_t st);
+int launch_zcol_bwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* grid_wh, const float* s,
+                    const float* dproj, const float* proj, const float* trans, float* dT, float* ds_part, float* dsmall,
+                    const LossArgs& la, hipStream_t st);
+int launch_loss_finalize(const float* sse, int S, int K, float inv_S, float* loss, int32_t* winner, hipStream_t st);
+
+}  // namespace dpck

@@ -1,0 +1,352 @@
+// Backward slab kernel: adjoint H pass from global dT, adjoint W pass at the gathered corners, 8-corner gather,
+// transform backward and the per-cloud reductions (k_gather_hw).  Design notes: DESIGN.md section 4.
+#include "dpc_kernels.h"
+
+DPC_DEBUG_SETTERS(bwd)
+
+namespace dpck {
+namespace {
+
+// ------------------------------------------------------------------------------------------------------
+// Backward 2: adjoint H/W passes + clamp mask + trilinear gather + transform backward.   grid (nslab, B)
+//   The slab holds cell layers [z0, z0+Zs) plus one halo plane so each point's 8 corners are local.
+// ------------------------------------------------------------------------------------------------------
+template <int GS, int ZS, int RB>
+__global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells cells, const float* __restrict__ pc,
+                                                            const float* __restrict__ q, const float* __restrict__ t,
+                                                            const float* __restrict__ f, TapsT<RB> taps_adj, int zs_rt,
+                                                            const float* __restrict__ dT,
+                                                            const uint64_t* __restrict__ mask,
+                                                            const float* __restrict__ ds_part, int n_ds_part,
+                                                            float* __restrict__ dpc, float* __restrict__ dsmall,
+                                                            LossArgs la) {
+  extern __shared__ __attribute__((aligned(16))) float slab[];
+  const int D = P.D, H = P.H, W = P.W, N = P.N, HW = H * W;
+  const int Zs = GS ? ZS : zs_rt;
+  // One-layer slabs (planes too big for more: 128^2) ROLL: the workgroup walks `roll` consecutive layers, keeps the plane
+  // two layers share in LDS (ping-pong of the two plane buffers) and pays start-up, reduction and atomics once.
+  constexpr bool kRolls = GS > 0 && ZS == 1 && RB > 0;
+  const int roll = kRolls ? zs_rt : 1;
+  const int b = blockIdx.y, z0 = blockIdx.x * Zs * roll;
+  const int reps = P.point_replicas > 1 ? P.point_replicas : 1;
+  const bool shared_points = reps > 1;  // dpc is [B/reps,N,3], zeroed by the caller; replicas add into it
+  if (cloud_loses(la, b)) {  // a losing pose candidate: zero gradient, no work (block-uniform)
+    if (shared_points) {
+      if (blockIdx.x == 0 && threadIdx.x == 0) dsmall[(size_t)DPC_COL_DS * P.B + b] = 0.f;
+      return;
+    }
+    float* dz = dpc + (size_t)b * N * 3;
+    auto zero3 = [&](const PointRec&, const int4* aux) {
+      const int i = aux->w;
+      dz[3 * i + 0] = 0.f; dz[3 * i + 1] = 0.f; dz[3 * i + 2] = 0.f;
+    };
+    for_each_record(cells, b, z0, min(z0 + Zs * roll, D), zero3);
+    if (blockIdx.x == 0) {
+      for_each_record(cells, b, D, D + 1, zero3);
+      if (threadIdx.x == 0) dsmall[(size_t)DPC_COL_DS * P.B + b] = 0.f;
+    }
+    return;
+  }
+  const int nzp = min(Zs + 1, D - z0);  // planes present (cell layers + halo)
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  // camera inputs and the upstream scalar: requested now, first used after the slab is in LDS
+  const CameraRaw cam_raw = load_camera_raw(P, q, t, f, b);
+  const float upstream = (la.scale_in_gather && la.dloss != nullptr) ? *la.dloss : 1.0f;
+  const int wpp = (HW + 63) / 64;
+  const float* src = dT + ((size_t)b * D + z0) * HW;
+  const uint64_t* mrow = mask + ((size_t)b * D + z0) * wpp;
+  float* red;
+
+  if constexpr (GS > 0) {
+    constexpr int NPL = ZS + 1;
+    using Geo = BwdGeo<GS, RB, NPL>;
+    red = slab + ((Geo::slab_floats(NPL) + 3) / 4) * 4;
+    RecordRange rr{0, 0};
+    if (cells.nblk <= DPC_WAVE) rr = load_record_range(cells, b, z0, min(z0 + Zs, D));  // in flight under the H-pass
+    const uint32_t* mask32 = reinterpret_cast<const uint32_t*>(mrow);
+    DPC_STAMP(8);
+    for (int i = tid; i < (NPL * GS + 1) * (Geo::PAD / 4); i += Geo::NT) {  // zero the row pads (W-pass halo)
+      const int p4 = i % (Geo::PAD / 4), row = i / (Geo::PAD / 4);
+      *reinterpret_cast<f32x4*>(slab + row * Geo::WP + 4 * p4) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (RB == 0) {
+      // planes -> LDS (16-byte global loads, 16-byte LDS stores); absent planes are zeroed
+      for (int i = tid; i < NPL * GS * (GS / 4); i += Geo::NT) {
+        const int x4 = i % (GS / 4), zy = i / (GS / 4);
+        f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (zy < nzp * GS) val = *reinterpret_cast<const f32x4*>(src + (size_t)zy * GS + 4 * x4);
+        *reinterpret_cast<f32x4*>(slab + zy * Geo::WP + Geo::PAD + 4 * x4) = val;
+      }
+      if (cells.nblk <= DPC_WAVE) finish_record_table(rr, reinterpret_cast<int*>(red + kRedTab));
+      __syncthreads();
+      const float w2 = taps_adj.w[0] * taps_adj.w[0];
+      for (int i = tid; i < NPL * GS * GS; i += Geo::NT) {
+        const int x = i % GS, zy = i / GS;
+        const bool pass = zy < nzp * GS && ((mask32[i >> 5] >> (i & 31)) & 1u);
+        float* cell = slab + zy * Geo::WP + Geo::PAD + x;
+        *cell = pass ? w2 * *cell : 0.f;
+      }
+      __syncthreads();
+    } else {
+      // adjoint H-pass with its windows read straight from global dT (lanes walk x: coalesced; the halo rows
+      // shared by neighbouring segments come from L1/L2), results stored to LDS once
+      // The adjoint W-pass is NOT run over the slab: only ~8 voxels per point are ever gathered (64k per cloud vs
+      // 262k voxels), so it is evaluated at the gathered corners below.  The clamp-mask words of the slab's planes
+      // are staged in LDS (requested now, stored after the H-pass so their latency hides under it).
+      constexpr int MW = NPL * GS * (GS / 32), MPT = (MW + Geo::NT - 1) / Geo::NT;
+      uint32_t mreg[MPT];
+#pragma unroll
+      for (int it = 0; it < MPT; ++it) {
+        const int w = tid + it * Geo::NT;
+        mreg[it] = (w < MW && w / (GS * (GS / 32)) < nzp) ? mask32[w] : 0u;
+      }
+      hpass_global<Geo, GS, RB, NPL>(src, nzp, taps_adj, [&](int z, int y, int x, f32x2 val) {
+        *reinterpret_cast<f32x2*>(slab + Geo::at(z, y, x)) = val;
+      });
+      uint32_t* mlds = reinterpret_cast<uint32_t*>(red + kRedMask);
+#pragma unroll
+      for (int it = 0; it < MPT; ++it) {
+        const int w = tid + it * Geo::NT;
+        if (w < MW) mlds[w] = mreg[it];
+      }
+      if (cells.nblk <= DPC_WAVE) finish_record_table(rr, reinterpret_cast<int*>(red + kRedTab));
+      __syncthreads();
+      DPC_STAMP(9);
+      DPC_STAMP(10);
+    }
+  } else {
+    const int WP = odd_stride(W);
+    red = slab + (size_t)(Zs + 1) * H * WP;
+    for (int i = tid; i < nzp * HW; i += nthr) {
+      const int x = i % W, zy = i / W;
+      slab[zy * WP + x] = src[i];
+    }
+    __syncthreads();
+    if (RB == 0) {
+      const float w2 = taps_adj.w[0] * taps_adj.w[0];
+      for (int i = tid; i < nzp * HW; i += nthr) {
+        const int z = i / HW, r = i - z * HW;
+        const int x = r % W, y = r / W;
+        const bool pass = (mrow[(size_t)z * wpp + (r >> 6)] >> (r & 63)) & 1ull;
+        slab[(z * H + y) * WP + x] = pass ? w2 * slab[(z * H + y) * WP + x] : 0.f;
+      }
+      __syncthreads();
+    } else {
+      hpass<RB>(slab, nzp, H, W, WP, taps_adj, [&](int z, int y, int x, float val) { slab[(z * H + y) * WP + x] = val; });
+      wpass_inplace<RB, false>(slab, nzp, H, W, WP, taps_adj, [&](int line, int x, float val) {
+        const int z = line / H, y = line - z * H;
+        const int bit = y * W + x;
+        return ((mrow[(size_t)z * wpp + (bit >> 6)] >> (bit & 63)) & 1ull) ? val : 0.f;
+      });
+    }
+  }
+
+  // gather: every in-bounds point belongs to the slab of its cell layer iz; slab 0 also zero-fills the
+  // gradient of the out-of-bounds points (bin D)
+  if (DPC_ABL(12)) return;
+  const Camera cam = make_camera(P, cam_raw);
+  CamGrad g;
+  camgrad_zero(g);
+  float* dcloud = dpc + (size_t)(b / reps) * N * 3;
+  auto corner = [&](int zz, int yy, int xx) -> float {
+    if constexpr (GS > 0) return slab[BwdGeo<GS, RB, ZS + 1>::at(zz, yy, xx)];
+    else return slab[(zz * H + yy) * odd_stride(W) + xx];
+  };
+  auto gather = [&](const PointRec& rec, const int4* aux) {
+    const int4 pt = *aux;  // {px, py, pz, original index}: one 16-byte load, issued next to the record's
+    const int i = pt.w;
+    const Cell c = cell_from_record(rec);
+    float cv[2][2][2];
+    if constexpr (GS > 0 && RB > 0) {
+      // adjoint W-pass evaluated right here, at the two x corners of each of the four (z,y) rows, then masked
+      using Geo = BwdGeo<GS, RB, ZS + 1>;
+      const uint32_t* mlds = reinterpret_cast<const uint32_t*>(red + kRedMask);
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          cv[k][j][0] = cv[k][j][1] = 0.f;
+          if ((c.iz + k < D) && (c.iy + j < GS)) {
+            const int plane = kRolls ? ((c.iz - z0 + k) & 1) : (c.iz - z0 + k);  // rolling: plane z lives in buffer (z - z0) & 1
+            const int row = plane * GS + c.iy + j;
+            const float* rp = slab + row * Geo::WP + Geo::PAD + c.ix - RB;  // x = ix-RB .. ix+1+RB, pads are zero
+            float v[2 * RB + 2];
+#pragma unroll
+            for (int i = 0; i < 2 * RB + 2; ++i) v[i] = rp[i];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+              float acc = 0.f;
+#pragma unroll
+              for (int tp = 0; tp < 2 * RB + 1; ++tp) acc = fmaf(taps_adj.w[tp], v[e + tp], acc);
+              const int x = c.ix + e;
+              const bool pass = x < GS && ((mlds[row * (GS / 32) + (x >> 5)] >> (x & 31)) & 1u);
+              cv[k][j][e] = pass ? acc : 0.f;
+            }
+          }
+        }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const bool ok = (c.iz + k < D) && (c.iy + j < H) && (c.ix + e < W);
+            cv[k][j][e] = ok ? corner(c.iz - z0 + k, c.iy + j, c.ix + e) : 0.f;
+          }
+    }
+    float dgz = 0.f, dgy = 0.f, dgx = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        dgz += (cv[1][a][e] - cv[0][a][e]) * c.wy[a] * c.wx[e];
+        dgy += (cv[a][1][e] - cv[a][0][e]) * c.wz[a] * c.wx[e];
+        dgx += (cv[a][e][1] - cv[a][e][0]) * c.wz[a] * c.wy[e];
+      }
+    dgz *= upstream; dgy *= upstream; dgx *= upstream;  // 1 unless dT was produced by the forward for dloss = 1
+    const float px = __int_as_float(pt.x), py = __int_as_float(pt.y), pz = __int_as_float(pt.z);
+    const Projected o = project_point(cam, px, py, pz);
+    float dpx, dpy, dpz;
+    project_point_bwd(cam, o, px, py, pz, dgz * (float)(D - 1), dgy * (float)(H - 1), dgx * (float)(W - 1), dpx, dpy, dpz, g);
+    if (shared_points) {
+      atomicAdd(dcloud + 3 * i + 0, dpx); atomicAdd(dcloud + 3 * i + 1, dpy); atomicAdd(dcloud + 3 * i + 2, dpz);
+    } else {
+      dcloud[3 * i + 0] = dpx; dcloud[3 * i + 1] = dpy; dcloud[3 * i + 2] = dpz;
+    }
+  };
+  if (!DPC_ABL(10)) {
+    if (GS > 0 && cells.nblk <= DPC_WAVE) for_each_record_flat(cells, b, reinterpret_cast<const int*>(red + kRedTab), gather);
+    else for_each_record(cells, b, z0, min(z0 + Zs, D), gather);
+  }
+  if constexpr (kRolls) {
+    using Geo = BwdGeo<GS, RB, 2>;
+    constexpr int MW1 = GS * (GS / 32), MPT1 = (MW1 + Geo::NT - 1) / Geo::NT;  // clamp-mask words of one plane
+    const uint32_t* mask32 = reinterpret_cast<const uint32_t*>(mrow);
+    uint32_t* mlds = reinterpret_cast<uint32_t*>(red + kRedMask);
+    int* tab = reinterpret_cast<int*>(red + kRedTab);
+    const bool flat = cells.nblk <= DPC_WAVE;
+    for (int l = 1; l < roll && z0 + l < D; ++l) {
+      __syncthreads();  // layer l-1 is gathered: plane z0+l-1 (buffer (l-1)&1 == (l+1)&1) and the record table are free
+      const int buf = (l + 1) & 1;
+      const bool present = z0 + l + 1 < D;
+      RecordRange rr{0, 0};
+      if (flat) rr = load_record_range(cells, b, z0 + l, z0 + l + 1);
+      uint32_t mreg[MPT1];
+#pragma unroll
+      for (int it = 0; it < MPT1; ++it) {
+        const int w = tid + it * Geo::NT;
+        mreg[it] = (w < MW1 && present) ? mask32[(size_t)(l + 1) * MW1 + w] : 0u;
+      }
+      hpass_global<Geo, GS, RB, 1>(src + (size_t)(l + 1) * HW, present ? 1 : 0, taps_adj, [&](int, int y, int x, f32x2 val) {
+        *reinterpret_cast<f32x2*>(slab + Geo::at(buf, y, x)) = val;
+      });
+#pragma unroll
+      for (int it = 0; it < MPT1; ++it) {
+        const int w = tid + it * Geo::NT;
+        if (w < MW1) mlds[buf * MW1 + w] = mreg[it];
+      }
+      if (flat) finish_record_table(rr, tab);
+      __syncthreads();
+      if (flat) for_each_record_flat(cells, b, tab, gather);
+      else for_each_record(cells, b, z0 + l, z0 + l + 1, gather);
+    }
+  }
+  DPC_STAMP(11);
+  if (blockIdx.x == 0 && !shared_points)
+    for_each_record(cells, b, D, D + 1, [&](const PointRec&, const int4* aux) {
+      const int i = aux->w;
+      dcloud[3 * i + 0] = 0.f; dcloud[3 * i + 1] = 0.f; dcloud[3 * i + 2] = 0.f;
+    });
+
+  float vals[13];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) vals[i] = g.m[i];
+  vals[9] = g.dt[0]; vals[10] = g.dt[1]; vals[11] = g.dt[2]; vals[12] = g.df;
+  if (DPC_ABL(13)) { if (vals[0] == 123.f) dsmall[0] = vals[1]; return; }
+  block_sum<13>(vals, red);
+  DPC_STAMP(12);
+  if (DPC_ABL(14)) { if (vals[0] == 123.f) dsmall[0] = vals[1]; return; }
+  if (tid == 0) {
+    float dq[4];
+    quaternion_grad(cam, vals, dq);
+    // dsmall is [DPC_SMALL_COLS][B] with dq stored as a [B,4] block, dt as a [B,3] block (see dpc_render.h)
+    float* dqb = dsmall + (size_t)DPC_COL_DQ * P.B + (size_t)b * 4;
+    float* dtb = dsmall + (size_t)DPC_COL_DT * P.B + (size_t)b * 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) atomicAdd(dqb + i, dq[i]);
+    if (t != nullptr)
+      for (int i = 0; i < 3; ++i) atomicAdd(dtb + i, vals[9 + i]);
+    if (f != nullptr) atomicAdd(dsmall + (size_t)DPC_COL_DF * P.B + b, vals[12]);
+    if (blockIdx.x == 0) {
+      float ds = 0.f;
+      for (int i = 0; i < n_ds_part; ++i) ds += ds_part[(size_t)b * n_ds_part + i];
+      dsmall[(size_t)DPC_COL_DS * P.B + b] = ds * upstream;
+    }
+  }
+  DPC_STAMP(13);
+}
+
+template <int GS, int ZS, int RB>
+int launch_gather_fast(const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
+                       const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask,
+                       const float* ds_part, int ntile, float* dpc, float* dsmall, const LossArgs& la, hipStream_t st) {
+  using Geo = BwdGeo<GS, RB, ZS + 1>;
+  // slab + scratch tail: reduction floats, record table, staged mask words
+  constexpr size_t lds = (((Geo::slab_floats(ZS + 1) + 3) / 4) * 4 + kRedMask + (ZS + 1) * GS * (GS / 32)) * sizeof(float);
+  static_assert(lds <= kLdsLimit, "backward slab does not fit LDS");
+  static_assert(kRedTab >= 13 * (Geo::NT / DPC_WAVE) && kRedMask >= kRedTab + kTabInts, "scratch tail layout");
+  auto kern = k_gather_hw<GS, ZS, RB>;
+  int rc = set_lds(kern, lds);
+  if (rc != DPC_OK) return rc;
+  // one-layer slabs roll over several layers per workgroup (see the kernel): as many as still leave a workgroup per CU
+  int roll = 1;
+  if (ZS == 1 && RB > 0)
+    for (int c = 2; c <= 16; c *= 2)
+      if (p->D % c == 0 && (size_t)(p->D / c) * p->B >= (size_t)kNumCUs) roll = c;
+  const int nslab = (p->D + ZS - 1) / ZS;
+  DPC_LAUNCH("k_gather_hw", kern, dim3((nslab + roll - 1) / roll, p->B), dim3(Geo::NT), lds, st, *p, cells, pc, q, t, f,
+             make_taps<RB>(kxy, pxy, true), ZS == 1 ? roll : ZS, dT, mask, ds_part, ntile, dpc, dsmall, la);
+  return launch_ok();
+}
+
+template <int RB>
+int launch_gather_rb(const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
+                  const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part,
+                  int ntile, float* dpc, float* dsmall, const LossArgs& la, hipStream_t st) {
+  if (p->H == p->W) {
+    if constexpr (RB <= 4) {
+      if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
+      if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
+      if (p->H == 64) return launch_gather_fast<64, kBwdZs64, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
+    } else if constexpr (RB <= 10) {
+      if (p->H == 64) return launch_gather_fast<64, 7, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
+      if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);  // c4: sigma_rel 1.28 -> radius 8
+      if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
+    }
+  }
+  const int fit = planes_fit(p);
+  if (fit < 2) return DPC_ERR_LDS;
+  const int Zs = std::min(fit - 1, std::max(1, (p->D + 7) / 8));
+  const size_t lds = ((size_t)(Zs + 1) * p->H * (p->W | 1) + kRedFloats) * sizeof(float);
+  auto kern = k_gather_hw<0, 0, RB>;
+  int rc = set_lds(kern, lds);
+  if (rc != DPC_OK) return rc;
+  DPC_LAUNCH("k_gather_hw", kern, dim3((p->D + Zs - 1) / Zs, p->B), dim3(slab_threads(p)), lds, st, *p, cells, pc, q, t, f,
+             make_taps<RB>(kxy, pxy, true), Zs, dT, mask, ds_part, ntile, dpc, dsmall, la);
+  return launch_ok();
+}
+
+}  // namespace
+
+int launch_gather(int bucket, const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
+                  const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part, int ntile,
+                  float* dpc, float* dsmall, const LossArgs& la, hipStream_t st) {
+  int rc = DPC_OK;
+#define DPC_GATHER(RB) rc = launch_gather_rb<RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st)
+  DPC_FOR_BUCKET(bucket, DPC_GATHER)
+#undef DPC_GATHER
+  return rc;
+}
+
+}  // namespace dpck

@@ -1,6 +1,6 @@
 // Stage-level entry points: one per reference function, for the sub-stage Python API
 // (pc_perspective_transform, pointcloud2voxels3d_fast backward, smoothen_voxels3d, drc_*) and as an
-// independent on-device cross-check of the fused path in dpc_fused.hip.  These favour generality (any grid
+// independent on-device cross-check of the fused path (dpc_entry.hip).  These favour generality (any grid
 // size, any tap count up to DPC_MAX_TAPS) over fusion; the hot path does not go through them.
 #include <math.h>
 

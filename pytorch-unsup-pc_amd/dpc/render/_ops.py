@@ -121,7 +121,7 @@ def locate_points(pc, q, t, f, geom):
 # Fused hot path
 # ------------------------------------------------------------------------------------------------------
 class ProjectFused(torch.autograd.Function):
-    """pointcloud_project_fast as three launches forward, two backward (csrc/dpc_fused.hip).
+    """pointcloud_project_fast as three launches forward, two backward (csrc/dpc_entry.hip and the kernel files it names).
 
     forward(pc [B,N,3], q [B,4], t [B,3]|None, f [B,1]|None, s [B,1]|None, geom) -> proj [B,H,W,1]
     Saved for backward: the binned point records, the grid after clamp + W/H passes, the clamp mask and the per-ray
