@@ -16,7 +16,7 @@ out = "gpurun_out/pmc"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"]); k = re.sub(r"\(.*", "", k).replace("void ", "").strip()
+        k = re.sub(r"\(anonymous namespace\)::|dpck::", "", r["Kernel_Name"]); k = re.sub(r"\(.*", "", k).replace("void ", "").strip()
         if k.startswith("k_"):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fh:

@@ -13,7 +13,7 @@ out = sys.argv[1]
 
 
 def short(name):
-    n = re.sub(r"\(anonymous namespace\)::", "", name)
+    n = re.sub(r"\(anonymous namespace\)::|dpck::", "", name)
     return re.sub(r"\(.*", "", n).replace("void ", "").strip()
 
 
