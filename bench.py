@@ -15,7 +15,8 @@ its own B=32 shard, no data-path collective; the per-step losses are all-reduced
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (per-kernel HIP-event timing from
 the library's opt-in profiler, eager pass after the timed region, minus one event marker's cost);
 `roofline_step` prices the whole step with
-the contractual algorithmic bytes A(N,G) of SURVEY.md 8(d); `cpu_baseline` times the CPU oracle (a port of the
+the contractual algorithmic bytes A(N,G) of SURVEY.md 8(d); `cpu_baseline` (the only part of this file that touches
+oracle/) times the CPU oracle (a port of the
 reference's PyTorch CPU path) on a bounded sample on this host.
 """
 import argparse
@@ -73,11 +74,20 @@ def measured_traffic(kernel):
     return None
 
 
-def make_inputs(device, seed):
-    from oracle.dpc_oracle import synth_inputs  # input generator only (shared with the tests)
+def synthetic_inputs(b, n, g, seed):
+    """Synthetic inputs of SURVEY.md 8(d): points like the decoder's tanh/2 output, unnormalised quaternions, occupancy
+    scales in (0.5, 1), and a random 2G x 2G mask average-pooled to the silhouette size (the reference's add_proj_loss)."""
+    gen = torch.Generator().manual_seed(seed)
+    pc = (torch.tanh(0.5 * torch.randn(b, n, 3, generator=gen)) / 2).float()
+    q = torch.randn(b, 4, generator=gen).float()
+    s = (0.5 + 0.5 * torch.rand(b, 1, generator=gen)).float()
+    mask = (torch.rand(b, 1, 2 * g, 2 * g, generator=gen) > 0.5).float()
+    gt = torch.nn.functional.avg_pool2d(mask, 2).permute(0, 2, 3, 1).contiguous()
+    return pc, q, s, gt
 
-    pc, q, s, gt, _, _ = synth_inputs(B, N_PTS, G, seed)
-    return [x.to(device=device, dtype=torch.float32) for x in (pc, q, s, gt)]
+
+def make_inputs(device, seed):
+    return [x.to(device=device, dtype=torch.float32) for x in synthetic_inputs(B, N_PTS, G, seed)]
 
 
 def cpu_baseline():
@@ -172,10 +182,10 @@ def main():
             dist.init_process_group("nccl", device_id=device)  # RCCL over xGMI
 
     import dpc.render as R
+    from dpc.harness import chair_unsupervised
     from dpc.render import _native
-    from oracle.dpc_oracle import Cfg
 
-    cfg = Cfg(vox_size=G, pc_gauss_kernel_size=KSIZE)
+    cfg = chair_unsupervised(vox_size=G, pc_gauss_kernel_size=KSIZE)  # the experiment's renderer settings; no oracle here
     kern = R.smoothing_kernel(cfg, SIGMA_REL)
     pc, q, s, gt = make_inputs(device, 1234 + rank)
     if K_CAND > 1:  # candidates of a sample share its cloud, scale and mask (tf_repeat_0); quaternions differ
