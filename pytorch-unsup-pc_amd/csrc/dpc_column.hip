@@ -118,7 +118,8 @@ template <int DD, int RB, int RPL>
 __global__ __launch_bounds__(kColThreads, (RPL * DD <= 128 ? 2 : 1))
 void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, const float* __restrict__ s, TapsT<RB> taps,
                    TapsT<RB> taps_adj, float* __restrict__ proj, float* __restrict__ dT, float* __restrict__ ds_part,
-                   int n_ds_part, unsigned long long* __restrict__ tickets, float* __restrict__ dsmall, LossArgs la) {
+                   int n_ds_part, unsigned long long* __restrict__ tickets, int batch_frac, float* __restrict__ dsmall,
+                   LossArgs la) {
   typedef float vec __attribute__((ext_vector_type(RPL)));
   const int HW = P.H * P.W;
   const int b = blockIdx.y, ray = RPL * (blockIdx.x * kColThreads + threadIdx.x);
@@ -259,7 +260,17 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
       const unsigned long long sum = (before + mine) & ((1ull << kSseCountShift) - 1);
       const float tot = (float)((double)sum * (1.0 / (double)(1ull << kSseFrac)));
       la.sse[b] = tot;
-      atomicAdd(la.loss_direct, tot * la.inv_S);
+      // The batch loss the same way, one level up: the clouds' exact sums go into one more 64-bit word (count in the top 16
+      // bits, batch_frac fractional bits chosen on the host so that B * H * W fits), and the cloud that arrives last writes
+      // the loss -- integer adds again, so the loss is bit-identical from run to run (float atomics here differed in the
+      // last bits with the arrival order).
+      const unsigned long long cmine =
+          (1ull << 48) | (unsigned long long)((double)sum * (1.0 / (double)(1ull << kSseFrac)) * (double)(1ull << batch_frac) + 0.5);
+      const unsigned long long cbefore = __hip_atomic_fetch_add(tickets + gridDim.y, cmine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((cbefore >> 48) == gridDim.y - 1) {
+        const unsigned long long total = (cbefore + cmine) & ((1ull << 48) - 1);
+        *la.loss_direct = (float)((double)total * (1.0 / (double)(1ull << batch_frac)) * (double)la.inv_S);
+      }
     }
   }
   if (blockIdx.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)threadIdx.x * gridDim.y + b] = 0.f;  // [col][B]
@@ -464,12 +475,16 @@ int launch_zcol_fwdbwd(const DpcParams* p, const float* host_kern_z, const TapPl
   const RayHost rh = ray_host(p);
   constexpr int kRpl = DPC_ZFB_RPL;
   dim3 gpair((p->H * p->W / kRpl + kColThreads - 1) / kColThreads, p->B);
+  // fractional bits of the batch word: the batch's squared error is below B * H * W * 1.0001 and must stay below 2^48
+  int batch_frac = 46;
+  for (double cap = (double)p->B * p->H * p->W * 1.001 + 1.0; cap > 1.0; cap *= 0.5) --batch_frac;
+  if (batch_frac < 0) batch_frac = 0;
 #define DPC_ZFB(RB)                                                                                                \
   {                                                                                                                \
     const TapsT<RB> tzf = make_taps<RB>(host_kern_z, pz, false), tza = make_taps<RB>(host_kern_z, pz, true);       \
-    if (p->D == 32) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<32, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, bwd_dsmall, la); \
-    else if (p->D == 64) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<64, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, bwd_dsmall, la); \
-    else DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<128, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, bwd_dsmall, la); \
+    if (p->D == 32) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<32, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, batch_frac, bwd_dsmall, la); \
+    else if (p->D == 64) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<64, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, batch_frac, bwd_dsmall, la); \
+    else DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<128, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, batch_frac, bwd_dsmall, la); \
   }
   DPC_FOR_BUCKET(pz.bucket, DPC_ZFB)
 #undef DPC_ZFB

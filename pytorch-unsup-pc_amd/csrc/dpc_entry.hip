@@ -25,7 +25,7 @@ size_t dpc_cells_bytes(const DpcParams* p) {
 size_t dpc_workspace_bytes(const DpcParams* p) {
   if (validate(p) != DPC_OK) return 0;
   const size_t grid = (size_t)p->B * p->D * p->H * p->W * sizeof(float);
-  const size_t parts = (size_t)p->B * col_tiles(p) * sizeof(float) + (size_t)p->B * 8 + 8;  // ds partials, sum-and-count words
+  const size_t parts = (size_t)p->B * col_tiles(p) * sizeof(float) + ((size_t)p->B + 1) * 8 + 8;  // ds partials; 8-byte aligned sum-and-count words (clouds + batch)
   return ((grid + 255) / 256) * 256 + ((parts + 255) / 256) * 256;
 }
 
@@ -85,7 +85,9 @@ int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const 
                         can_fuse_column_backward(p, pz, la.K, Tbuf, proj, la.gt, bwd_workspace);
   const size_t grid_bytes = (((size_t)p->B * p->D * p->H * p->W * sizeof(float) + 255) / 256) * 256;
   float* ds_part = fuse_bwd ? reinterpret_cast<float*>(static_cast<char*>(bwd_workspace) + grid_bytes) : nullptr;
-  unsigned long long* tickets = fuse_bwd ? reinterpret_cast<unsigned long long*>(ds_part + (size_t)p->B * col_tiles(p)) : nullptr;
+  unsigned long long* tickets = nullptr;  // B per-cloud words + 1 batch word behind the ds partials, 8-byte aligned
+  if (fuse_bwd)
+    tickets = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(ds_part + (size_t)p->B * col_tiles(p)) + 7u) & ~(uintptr_t)7u);
   if ((rc = launch_splat(pxy.bucket, p, cv, host_kern_xy, pxy, raw, Tbuf, mask, la.sse, la.loss_direct, la.winner_out, tickets, st)) != DPC_OK)
     return rc;
   if (fuse_bwd)

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
     sse[blockIdx.y] = 0.f;
     if (winner_zero != nullptr) winner_zero[blockIdx.y] = 0;   // K == 1: sample == cloud, candidate 0 wins
     if (ticket_zero != nullptr) ticket_zero[blockIdx.y] = 0ull;  // k_zcol_fwdbwd's per-cloud sum-and-count word
+    if (ticket_zero != nullptr && blockIdx.y == 0) ticket_zero[gridDim.y] = 0ull;  // ... and the batch's, behind them
     if (loss_zero != nullptr && blockIdx.y == 0) *loss_zero = 0.f;
   }
   const int D = P.D, H = P.H, W = P.W;
