@@ -16,6 +16,18 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def native_library():
+    """The tests bind libdpc_render.so; a checkout that has not been built yet is built here (hipcc cross-compiles for
+    gfx950 without a GPU, a few minutes) instead of failing on the first test that loads it."""
+    lib = os.path.join(PKG, "csrc", "libdpc_render.so")
+    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+        import subprocess
+
+        subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "-j3"], check=True, stdout=subprocess.DEVNULL)
+    return lib
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

@@ -54,7 +54,7 @@ def main():
             if i % 500 == 499:
                 side.synchronize()
                 for k, (a, b) in enumerate(zip((loss, proj, pc.grad, q.grad, s.grad), ref)):
-                    d = float((a - b).abs().max())
+                    d = float((a.detach() - b).abs().max())
                     worst[k] = max(worst[k], d)
                     if (exact[k] and d != 0.0) or not torch.isfinite(a).all() or d > 1e-4 * max(1.0, float(b.abs().max())):
                         print("DEVIATION at replay", i, names[k], d)
