@@ -495,6 +495,31 @@ def test_shared_point_sets(R, O, K, reps, sig, G):
         R.pointcloud_project_fast(cfg, dev(pc[:2]), dev(q[:3]), None, None, kern)
 
 
+def test_graphed_project_loss(R, O):
+    """The graph-captured step for eager loops: same loss and gradients as the eager call, on the sample data and on new
+    data of the same shapes, called repeatedly."""
+    import warnings
+
+    B, N, G = 6, 1500, 32
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    kern = R.smoothing_kernel(cfg, 0.64)
+    pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 808)
+    leafs = lambda scale=1.0: [dev(pc * scale, True), dev(q, True), dev(s, True), dev(gt)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        step = R.graphed_project_loss(cfg, kern, *leafs())
+        for scale in (1.0, 0.8, 0.8):
+            a, b = leafs(scale), leafs(scale)
+            le = R.pointcloud_project_loss(cfg, a[0], a[1], None, None, kern, scaling_factor=a[2], gt=a[3])[0]
+            le.backward()
+            lg = step(*b)
+            lg.backward()
+            assert float(le.detach()) == float(lg.detach())
+            assert torch.equal(a[0].grad, b[0].grad)
+            close(b[1].grad, a[1].grad, 1e-6, "graphed step: dq")
+            close(b[2].grad, a[2].grad, 1e-6, "graphed step: ds")
+
+
 def test_config4_full_size(R, O):
     """BASELINE config 4 per-GPU shard: 8 clouds x 16000 pts -> 128^3, sigma = 0.01 (sigma_rel 1.28), 21 taps.
     Size-independent properties on all 8 clouds + the oracle on one of them (128^3 fp64 on CPU takes seconds)."""
