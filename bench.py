@@ -190,7 +190,7 @@ def main():
     pc, q, s, gt = make_inputs(device, 1234 + rank)
     if K_CAND > 1:  # candidates of a sample share its cloud, scale and mask (tf_repeat_0); quaternions differ
         S = B // K_CAND
-        pc = pc[:S].repeat_interleave(K_CAND, dim=0).contiguous()
+        pc = pc[:S].contiguous()  # shared point sets: [S,N,3] read in place by the K clouds of a sample (no tf_repeat_0 copy)
         s = s[:S].repeat_interleave(K_CAND, dim=0).contiguous()
         gt = gt[:S].contiguous()
     pc.requires_grad_(True), q.requires_grad_(True), s.requires_grad_(True)
@@ -199,6 +199,8 @@ def main():
     ns = max(1, args.streams)
     if B % ns:
         raise SystemExit("--streams must divide %d" % B)
+    if ns > 1 and K_CAND > 1:
+        raise SystemExit("--streams is an experiment of the one-candidate configs")
     # per-stream shards (leaves of their own, so each shard's backward accumulates into its own .grad)
     shards = [[x[i * (x.shape[0] // ns):(i + 1) * (x.shape[0] // ns)].detach().clone().requires_grad_(x.requires_grad)
                for x in (pc, q, s, gt)] for i in range(ns)]
