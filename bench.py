@@ -12,6 +12,11 @@ sum((proj-gt)^2)/B, and the hand-written backward to d(pc), d(q), d(s).  Workloa
 (sigma_rel 0.64).  The step is captured once into a HIP graph and replayed; weak scaling (every rank runs
 its own B=32 shard, no data-path collective; the per-step losses are all-reduced once after the timed loop).
 
+`--gpus N` without a launcher starts the N ranks itself (a child `python -m torch.distributed.run ... bench.py` started
+before anything in this process touches a GPU) and relays rank 0's line; under torchrun (WORLD_SIZE set) it is a rank.
+`--config c3` runs BASELINE configs[2], the full chair_unsupervised training step (networks + renderer + loss + Adam), one
+shard of 8 objects per rank with the parameter gradients all-reduced over RCCL in buckets, overlapped with the backward.
+
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (per-kernel HIP-event timing from
 the library's opt-in profiler, eager pass after the timed region, minus one event marker's cost);
 `roofline_step` prices the whole step with
@@ -47,30 +52,46 @@ def algorithmic_bytes_per_cloud(n, g):
 
 
 def kernel_bytes_per_cloud(n, g):
-    """Bytes each launch of THIS implementation must move per cloud (kernel table)."""
+    """Bytes each launch of THIS implementation must move per cloud (kernel table): the tensors a launch has to
+    read or write once, whatever the cache does.  Chunk of 256 points = 256 x (16 B record + 16 B {point, index}) + bin
+    offsets; optional outputs (`smoothed`, `trans`) are not written on the hot path and not counted."""
     g3, g2 = g ** 3, g ** 2
+    cells = 32 * n + ((n + 255) // 256) * (((g + 2) * 2 + 15) // 16) * 16   # binned records + per-chunk bin offsets
     return {
-        "k_locate": 12 * n + 16 * n,                    # read pc, write point records
-        "k_splat_hw": 16 * n + 4 * g3 + g3 // 8,        # read records, write T (after W/H passes) + clamp mask
-        "k_zcol_fwd": 4 * g3 + 4 * g3 + 4 * g2,         # read T, write smoothed grid, write silhouette
-        "k_zcol_bwd": 4 * g3 + 4 * g2 + 4 * g3,         # read smoothed grid + dproj, write dT
-        "k_zcol_fwdbwd": 4 * g3 + 4 * g3 + 8 * g2,      # read T + gt, write dT + silhouette (column backward fused)
-        "k_gather_hw": 4 * g3 + g3 // 8 + 16 * n + 24 * n,  # read dT + mask + records + pc, write dpc
+        "k_locate": 12 * n + cells,                       # read pc, write the binned records
+        "k_splat_hw": 16 * n + 4 * g3 + g3 // 8,          # read records, write T (after W/H passes) + clamp mask
+        "k_zcol_fwd": 4 * g3 + 4 * g2,                    # read T, write silhouette
+        "k_zcol_bwd": 4 * g3 + 4 * g3 + 8 * g2,           # read T + dproj (or proj, gt), write dT
+        "k_zcol_fwdbwd": 4 * g3 + 4 * g3 + 8 * g2,        # read T + gt, write dT + silhouette (column backward fused)
+        "k_gather_hw": 4 * g3 + g3 // 8 + 32 * n + 12 * n,  # read dT + mask + records with their points, write dpc
     }
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (FETCH_SIZE / WRITE_SIZE collected
-    in separate passes by tools/profile_gpu.sh and corrected with the calibration kernels, as MI355X_MICROARCH.md
-    prescribes); None when no profile of this kernel is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_rocprof_summary.json")
-    try:
-        kernels = json.load(open(path))["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    for name, rec in kernels.items():
-        if name.split("<")[0] == kernel and rec.get("hbm_bytes_per_launch"):
-            return rec["hbm_bytes_per_launch"]
+def step_bytes_per_cloud(n, g, k_cand):
+    """Contractual bytes of one cloud of the step that is actually run: A(N,G) for one pose candidate per sample; with K
+    candidates only the winning cloud of a sample runs a backward, so the backward share counts 1/K."""
+    fwd = 12 * n + 16 * g ** 3 + 4 * g ** 2
+    bwd = algorithmic_bytes_per_cloud(n, g) - fwd
+    return fwd + bwd / k_cand
+
+
+PROFILE_SUMMARIES = ("r02_rocprof_summary.json", "r01_rocprof_summary.json")   # newest first
+
+
+def measured_traffic(kernel, config="c2"):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of THIS config (FETCH_SIZE / WRITE_SIZE
+    collected in separate passes by tools/profile_gpu.sh and corrected with the calibration kernels, as
+    MI355X_MICROARCH.md prescribes); None when no profile of this kernel at this config is on file."""
+    for name in PROFILE_SUMMARIES:
+        try:
+            summary = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if summary.get("config", "c2") != config:
+            continue
+        for kname, rec in summary.get("kernels", {}).items():
+            if kname.split("<")[0] == kernel and rec.get("hbm_bytes_per_launch"):
+                return rec["hbm_bytes_per_launch"]
     return None
 
 
@@ -143,6 +164,104 @@ def cpu_baseline():
             "value_1thread": single, "cpu_model": model, "host_cpus": os.cpu_count()}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks as `python -m torch.distributed.run`
+    children (one process per GPU, RCCL over xGMI) and relay their output.  Nothing in THIS process has initialised a GPU
+    (device_count() does not), so no process that has touched a GPU ever re-execs.  Returns the exit code."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < args.gpus and not args.rehearse_on_one_gpu:
+        sys.stderr.write("bench.py: --gpus %d but this node shows %d device(s); nothing was run\n" % (args.gpus, have))
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def full_step_main(args, rank, world, local):
+    """BASELINE configs[2]: the chair_unsupervised training step per rank (8 objects x 4 views = 32 images 128x128, K = 4
+    pose candidates -> 128 clouds of 8000 points into 64^3; networks + renderer + loss + backward + Adam, fp32, eager),
+    weak scaling: every rank owns 8 objects, the parameter gradients (133 MB) are summed over RCCL in buckets launched from
+    autograd hooks while the backward is still running (dpc.render.parallel.OverlappedGradAllReduce)."""
+    if args.rehearse_on_one_gpu:
+        local = 0
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if args.rehearse_on_one_gpu else "nccl",
+                                **({} if args.rehearse_on_one_gpu else {"device_id": device}))
+    from dpc.harness import TrainStep, chair_unsupervised
+    from dpc.render.parallel import OverlappedGradAllReduce
+
+    cfg = chair_unsupervised(pc_point_dropout=args.keep)
+    torch.manual_seed(0)                      # same initial weights on every rank
+    step = TrainStep(cfg, device, device_dropout=True)
+    sync = None
+    if world > 1:
+        sync = OverlappedGradAllReduce(step.nets.parameters(), bucket_mb=32, overlap=not args.no_overlap)
+        step.grad_sync, step.sync_samples = sync, (cfg.batch_size, cfg.batch_size * world)
+    nimg = cfg.batch_size * cfg.step_size
+    gen = torch.Generator().manual_seed(1234 + rank)
+    images = torch.rand(nimg, 3, 128, 128, generator=gen).to(device)
+    masks = (torch.rand(nimg, 1, 128, 128, generator=gen) > 0.5).float().to(device)
+    for _ in range(args.warmup):
+        step(images, masks)
+    torch.cuda.synchronize(device)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step(images, masks)
+    torch.cuda.synchronize(device)
+    mine = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    wall = time.perf_counter() - t0
+    times = torch.tensor([wall, mine], device=device, dtype=torch.float64)
+    per_rank = [times.clone() for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, times)
+    wall = max(float(t[0]) for t in per_rank)
+    comm = None
+    if sync is not None:   # the exchange alone, nothing else on the GPU: what overlapping has to hide
+        torch.cuda.synchronize(device)
+        c0 = time.perf_counter()
+        for _ in range(5):
+            sync.exchange_only()
+        torch.cuda.synchronize(device)
+        comm = (time.perf_counter() - c0) / 5
+    if rank == 0:
+        clouds = nimg * cfg.pose_predict_num_candidates
+        print(json.dumps({
+            "metric": "point-clouds/sec rendered inside the full chair_unsupervised train step (fwd + loss + bwd + grad all-reduce + Adam)",
+            "value": world * clouds * args.steps / wall, "unit": "point-clouds/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2] (c3): per rank 8 objects x 4 views (32 images 128x128x3), K=4 pose "
+                                   "candidates -> 128 clouds x %d of 8000 pts -> 64^3, 21 taps sigma_rel 3.0, eager launches"
+                                   % int(8000 * args.keep),
+                       "parameters": sum(p.numel() for p in step.nets.parameters()),
+                       "gradient_exchange": None if sync is None else
+                       {"backend": dist.get_backend(), "buckets": sync.num_buckets, "bytes": sync.nbytes,
+                        "overlapped_with_backward": not args.no_overlap}},
+            "train_steps_per_sec": world * args.steps / wall,
+            "ms_per_step_by_rank": [1e3 * float(t[1]) / args.steps for t in per_rank],
+            "allreduce_alone_ms": None if comm is None else 1e3 * comm,
+            "allreduce_exposed_ms": None if sync is None else 1e3 * sync.exposed_seconds / max(1, sync.steps),
+            "loss": float(loss)}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -153,23 +272,36 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the median/best windows and the forward-only timing "
                     "(profiling runs: keeps every traced kernel inside the contract's fwd+bwd step)")
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c2", help="BASELINE config (default c2 = the metric's)")
+    ap.add_argument("--config", choices=sorted(CONFIGS) + ["c3"], default="c2",
+                    help="BASELINE config (default c2 = the metric's); c3 = the full training step with the RCCL gradient exchange")
+    ap.add_argument("--keep", type=float, default=1.0, help="c3: point keep-probability of the dropout (1.0 = all 8000 points)")
+    ap.add_argument("--no-overlap", action="store_true", help="c3: all-reduce after the backward instead of inside it")
     ap.add_argument("--api", choices=["fused", "plain"], default="fused",
                     help="fused: pointcloud_project_loss (renderer + loss in one autograd node, the default and the contract "
                          "line); plain: the reference's own call sequence, pointcloud_project_fast then the loss in torch")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single-GPU box: every rank uses cuda:0 and the collectives run over gloo")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))   # this process never touches a GPU: the N ranks are its children
     global B, N_PTS, G, SIGMA_REL, K_CAND
-    B, N_PTS, G, SIGMA_REL, K_CAND = CONFIGS[args.config]
+    if args.config != "c3":
+        B, N_PTS, G, SIGMA_REL, K_CAND = CONFIGS[args.config]
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start the ranks with `python bench.py --gpus N` or with "
+                         "`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in dpc.render)")
+    if not args.rehearse_on_one_gpu and torch.cuda.device_count() < world:
+        raise SystemExit("--gpus %d but this node shows %d device(s)" % (world, torch.cuda.device_count()))
+    if args.config == "c3":
+        return full_step_main(args, rank, world, local)
     if args.rehearse_on_one_gpu:
         local = 0
     torch.cuda.set_device(local)
@@ -327,15 +459,17 @@ def main():
 
     clouds_per_s = world * B * args.steps / wall
     ms_per_step = 1e3 * wall / args.steps
-    a_bytes = algorithmic_bytes_per_cloud(N_PTS, G)
+    a_bytes = step_bytes_per_cloud(N_PTS, G, K_CAND)   # = A(N,G) of SURVEY 8(d) when every cloud runs its backward
     kb = kernel_bytes_per_cloud(N_PTS, G)
     dom = max(kern_ms, key=kern_ms.get) if kern_ms else None
+    # clouds a launch really works on: the backward kernels skip the losing pose candidates
+    live = {k: (B // K_CAND if k in ("k_zcol_bwd", "k_gather_hw") else B) for k in kb}
     roofline = None
     if dom is not None:
-        ach = B * kb[dom] / (kern_ms[dom] * 1e-3) / 1e9
+        ach = live[dom] * kb[dom] / (kern_ms[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(dom), "avg_launch_us": 1e3 * kern_ms[dom],
-                    "algorithmic_bytes_per_launch": B * kb[dom]}
+                    "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(dom, args.config), "avg_launch_us": 1e3 * kern_ms[dom],
+                    "algorithmic_bytes_per_launch": live[dom] * kb[dom]}
     step_ach = (B * a_bytes) / (dev_ms * 1e-3 / args.steps) / 1e9
     out = {
         "metric": "point-clouds/sec (8000 pts->64^3->128^2 proj) fwd+bwd", "value": clouds_per_s,
@@ -354,9 +488,10 @@ def main():
         "roofline_step": {"bound": "hbm", "achieved": step_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": step_ach / HBM_PEAK_GBS, "algorithmic_bytes_per_cloud": a_bytes,
                           "device_ms_per_step": dev_ms / args.steps,
-                          "note": "whole fwd+bwd step on rank 0 (HIP events on the launch stream) priced with A(N,G) of SURVEY 8(d)"},
+                          "note": "whole fwd+bwd step on rank 0 (HIP events on the launch stream) priced with A(N,G) of SURVEY 8(d)"
+                                  + ("" if K_CAND == 1 else "; losing pose candidates run no backward, their backward bytes are not counted")},
         "kernels_us": {k: 1e3 * v for k, v in sorted(kern_ms.items())},
-        "kernels_gbs": {k: B * kb[k] / (v * 1e-3) / 1e9 for k, v in sorted(kern_ms.items()) if k in kb},
+        "kernels_gbs": {k: live[k] * kb[k] / (v * 1e-3) / 1e9 for k, v in sorted(kern_ms.items()) if k in kb},
         "loss_mean": float(loss_t.item() / world),
     }
     out.update(extras)

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_fwd(Dp
                                                           float* __restrict__ smoothed, float* __restrict__ proj,
                                                           float* __restrict__ trans_out, LossArgs la) {
   const int HW = P.H * P.W;
-  const int b = blockIdx.y, ray = blockIdx.x * kColThreads + threadIdx.x;
+  const Blk bk = block_coords(P.B);
+  const int b = bk.y, ray = bk.x * kColThreads + threadIdx.x;
   const bool live = ray < HW;
   const RayConst rc = ray_const(rh, s, b);
   double trans = 1.0;
@@ -122,7 +123,8 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
                    LossArgs la) {
   typedef float vec __attribute__((ext_vector_type(RPL)));
   const int HW = P.H * P.W;
-  const int b = blockIdx.y, ray = RPL * (blockIdx.x * kColThreads + threadIdx.x);
+  const Blk bk = block_coords(P.B);
+  const int b = bk.y, ray = RPL * (bk.x * kColThreads + threadIdx.x);
   const bool live = ray < HW;
   const RayConst rc = ray_const(rh, s, b);
   float sq = 0.f, ds_acc = 0.f;
@@ -255,8 +257,8 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
     float dst = 0.f;
     for (int i = 0; i < kColThreads / DPC_WAVE; ++i) dst += red[1][i];
     // k_gather_hw sums n_ds_part partials per cloud (one per kColThreads rays); with RPL > 1 this grid has fewer blocks
-    for (int i = blockIdx.x; i < n_ds_part; i += gridDim.x) ds_part[(size_t)b * n_ds_part + i] = i == (int)blockIdx.x ? dst : 0.f;
-    if ((before >> kSseCountShift) == gridDim.x - 1) {  // every other block of this cloud has added its share
+    for (int i = bk.x; i < n_ds_part; i += bk.nx) ds_part[(size_t)b * n_ds_part + i] = i == bk.x ? dst : 0.f;
+    if ((int)(before >> kSseCountShift) == bk.nx - 1) {  // every other block of this cloud has added its share
       const unsigned long long sum = (before + mine) & ((1ull << kSseCountShift) - 1);
       const float tot = (float)((double)sum * (1.0 / (double)(1ull << kSseFrac)));
       la.sse[b] = tot;
@@ -266,14 +268,14 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
       // last bits with the arrival order).
       const unsigned long long cmine =
           (1ull << 48) | (unsigned long long)((double)sum * (1.0 / (double)(1ull << kSseFrac)) * (double)(1ull << batch_frac) + 0.5);
-      const unsigned long long cbefore = __hip_atomic_fetch_add(tickets + gridDim.y, cmine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((cbefore >> 48) == gridDim.y - 1) {
+      const unsigned long long cbefore = __hip_atomic_fetch_add(tickets + bk.ny, cmine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((int)(cbefore >> 48) == bk.ny - 1) {
         const unsigned long long total = (cbefore + cmine) & ((1ull << 48) - 1);
         *la.loss_direct = (float)((double)total * (1.0 / (double)(1ull << batch_frac)) * (double)la.inv_S);
       }
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)threadIdx.x * gridDim.y + b] = 0.f;  // [col][B]
+  if (bk.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)threadIdx.x * bk.ny + b] = 0.f;  // [col][B]
 }
 
 // Generic depth / tap count: same arithmetic, column re-read from global (L1/L2 serve the re-reads).
@@ -282,7 +284,8 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_fwd_dyn(DpcParams P, RayHo
                                                               float* __restrict__ smoothed, float* __restrict__ proj,
                                                               float* __restrict__ trans_out, LossArgs la) {
   const int HW = P.H * P.W, D = P.D;
-  const int b = blockIdx.y, ray = blockIdx.x * kColThreads + threadIdx.x;
+  const Blk bk = block_coords(P.B);
+  const int b = bk.y, ray = bk.x * kColThreads + threadIdx.x;
   const bool live = ray < HW;
   const RayConst rc = ray_const(rh, s, b);
   double trans = 1.0;
@@ -326,7 +329,8 @@ __device__ inline float ray_grad(const DpcParams& P, const LossArgs& la, const f
   return 2.0f * la.inv_S * up * (proj[(size_t)b * HW + pix] - la.gt[(size_t)(b / la.K) * HW + pix]);
 }
 
-__device__ inline void zcol_bwd_epilogue(float ds_acc, float* ds_part, float* dsmall, int b) {
+__device__ inline void zcol_bwd_epilogue(float ds_acc, float* ds_part, float* dsmall, const Blk& bk) {
+  const int b = bk.y;
   __shared__ float red[kColThreads / DPC_WAVE];
   const float w = wave_sum(ds_acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
@@ -334,9 +338,9 @@ __device__ inline void zcol_bwd_epilogue(float ds_acc, float* ds_part, float* ds
   if (threadIdx.x == 0) {
     float tot = 0.f;
     for (int i = 0; i < kColThreads / DPC_WAVE; ++i) tot += red[i];
-    ds_part[(size_t)b * gridDim.x + blockIdx.x] = tot;
+    ds_part[(size_t)b * bk.nx + bk.x] = tot;
   }
-  if (blockIdx.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)threadIdx.x * gridDim.y + b] = 0.f;  // [col][B]
+  if (bk.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)threadIdx.x * bk.ny + b] = 0.f;  // [col][B]
 }
 
 // Reads the grid saved by the forward slab kernel (after clamp + W/H passes), recomputes the forward D-pass in
@@ -351,7 +355,8 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
                                                           float* __restrict__ dT, float* __restrict__ ds_part,
                                                           float* __restrict__ dsmall, LossArgs la) {
   const int HW = P.H * P.W;
-  const int b = blockIdx.y, ray = blockIdx.x * kColThreads + threadIdx.x;
+  const Blk bk = block_coords(P.B);
+  const int b = bk.y, ray = bk.x * kColThreads + threadIdx.x;
   float ds_acc = 0.f;
   if (ray < HW && !cloud_loses(la, b)) {
     const RayConst rc = ray_const(rh, s, b);
@@ -407,7 +412,7 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
       if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   }
-  zcol_bwd_epilogue(ds_acc, ds_part, dsmall, b);
+  zcol_bwd_epilogue(ds_acc, ds_part, dsmall, bk);
 }
 
 __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHost rh, const float* __restrict__ Tin,
@@ -418,7 +423,8 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHo
                                                               float* __restrict__ dT, float* __restrict__ ds_part,
                                                               float* __restrict__ dsmall, LossArgs la) {
   const int HW = P.H * P.W, D = P.D;
-  const int b = blockIdx.y, ray = blockIdx.x * kColThreads + threadIdx.x;
+  const Blk bk = block_coords(P.B);
+  const int b = bk.y, ray = bk.x * kColThreads + threadIdx.x;
   float ds_acc = 0.f;
   if (ray < HW && !cloud_loses(la, b)) {
     const RayConst rc = ray_const(rh, s, b);
@@ -463,7 +469,7 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHo
       out[(size_t)z * HW] = acc;
     }
   }
-  zcol_bwd_epilogue(ds_acc, ds_part, dsmall, b);
+  zcol_bwd_epilogue(ds_acc, ds_part, dsmall, bk);
 }
 
 }  // namespace
@@ -474,7 +480,7 @@ int launch_zcol_fwdbwd(const DpcParams* p, const float* host_kern_z, const TapPl
   int rc = DPC_OK;
   const RayHost rh = ray_host(p);
   constexpr int kRpl = DPC_ZFB_RPL;
-  dim3 gpair((p->H * p->W / kRpl + kColThreads - 1) / kColThreads, p->B);
+  dim3 gpair(((p->H * p->W / kRpl + kColThreads - 1) / kColThreads) * p->B);
   // fractional bits of the batch word: the batch's squared error is below B * H * W * 1.0001 and must stay below 2^48
   int batch_frac = 46;
   for (double cap = (double)p->B * p->H * p->W * 1.001 + 1.0; cap > 1.0; cap *= 0.5) --batch_frac;
@@ -495,7 +501,7 @@ int launch_zcol_fwd(const DpcParams* p, const float* host_kern_z, const TapPlan&
                     float* smoothed, float* proj, float* trans, const LossArgs& la, hipStream_t st) {
   int rc = DPC_OK;
   const RayHost rh = ray_host(p);
-  dim3 gcol(col_tiles(p), p->B);
+  dim3 gcol(col_tiles(p) * p->B);
   bool done = false;
 #define DPC_ZFWD(RB)                                                                                             \
   {                                                                                                              \
@@ -519,7 +525,7 @@ int launch_zcol_bwd(const DpcParams* p, const float* host_kern_z, const TapPlan&
                     const LossArgs& la, hipStream_t st) {
   int rc = DPC_OK;
   const RayHost rh = ray_host(p);
-  dim3 gcol(col_tiles(p), p->B);
+  dim3 gcol(col_tiles(p) * p->B);
   bool done = false;
 #define DPC_ZBWD(RB)                                                                                              \
   {                                                                                                               \

@@ -21,7 +21,7 @@ static __device__ unsigned long long* g_dpc_stamps = nullptr;
 #define DPC_STAMP(slot)                                                                                    \
   do {                                                                                                     \
     if (g_dpc_stamps != nullptr && threadIdx.x == 0)                                                       \
-      g_dpc_stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
+      g_dpc_stamps[(size_t)blockIdx.x * 16 + (slot)] = __builtin_amdgcn_s_memrealtime(); \
   } while (0)
 #define DPC_DEBUG_SETTERS(tag)                                                                                          \
   extern "C" int dpc_debug_set_ablate_##tag(int v) {                                                                    \
@@ -54,6 +54,35 @@ constexpr int kRedTab = 256;     // float offset of the record table inside the 
 constexpr int kRedMask = 400;    // float offset of the staged clamp-mask words
 constexpr int kRedFloats = 1024; // generic kernels: reduction scratch (13 x 16 floats) + record table
 constexpr int kLdsBudget = kLdsLimit - 4096;         // generic slab bytes; the rest holds the reduction scratch
+
+// ------------------------------------------------------------------------------------------------------
+// Workgroup -> (part, cloud).  Every grid of the path is (parts per cloud) x (clouds), launched 1-D.  The eight XCDs of
+// the chip have private L2s and workgroups are dealt to them round-robin by linear id (MI355X_MICROARCH.md, "Workgroup
+// dispatch"), so the map sends ALL workgroups of cloud c, in every kernel, to the XCD group c % 8: what one kernel of
+// the chain writes for a cloud (point records, the W/H grid, dT: plain stores keep their lines in the writer's L2) is
+// read by the next kernel from the same L2 instead of from HBM.  Placement is a speed matter only; nothing depends on it.
+// ------------------------------------------------------------------------------------------------------
+struct Blk {
+  int x, y;    // part index (chunk / slab / ray tile), cloud
+  int nx, ny;  // parts per cloud, clouds
+};
+__device__ inline Blk block_coords(int clouds) {
+  Blk k;
+  k.ny = clouds;
+  k.nx = (int)gridDim.x / clouds;
+  const int L = blockIdx.x;
+#ifndef DPC_NO_XCD_MAP
+  if ((clouds & 7) == 0) {
+    const int q = L >> 3;
+    k.y = (L & 7) + 8 * (q / k.nx);
+    k.x = q % k.nx;
+    return k;
+  }
+#endif
+  k.y = L / k.nx;
+  k.x = L - k.y * k.nx;
+  return k;
+}
 
 __device__ inline int odd_stride(int w) { return w | 1; }  // generic LDS row stride: odd => conflict-free column walks
 

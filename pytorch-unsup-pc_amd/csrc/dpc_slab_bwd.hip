@@ -27,12 +27,13 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   // two layers share in LDS (ping-pong of the two plane buffers) and pays start-up, reduction and atomics once.
   constexpr bool kRolls = GS > 0 && ZS == 1 && RB > 0;
   const int roll = kRolls ? zs_rt : 1;
-  const int b = blockIdx.y, z0 = blockIdx.x * Zs * roll;
+  const Blk bk = block_coords(P.B);
+  const int b = bk.y, z0 = bk.x * Zs * roll;
   const int reps = P.point_replicas > 1 ? P.point_replicas : 1;
   const bool shared_points = reps > 1;  // dpc is [B/reps,N,3], zeroed by the caller; replicas add into it
   if (cloud_loses(la, b)) {  // a losing pose candidate: zero gradient, no work (block-uniform)
     if (shared_points) {
-      if (blockIdx.x == 0 && threadIdx.x == 0) dsmall[(size_t)DPC_COL_DS * P.B + b] = 0.f;
+      if (bk.x == 0 && threadIdx.x == 0) dsmall[(size_t)DPC_COL_DS * P.B + b] = 0.f;
       return;
     }
     float* dz = dpc + (size_t)b * N * 3;
@@ -41,7 +42,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
       dz[3 * i + 0] = 0.f; dz[3 * i + 1] = 0.f; dz[3 * i + 2] = 0.f;
     };
     for_each_record(cells, b, z0, min(z0 + Zs * roll, D), zero3);
-    if (blockIdx.x == 0) {
+    if (bk.x == 0) {
       for_each_record(cells, b, D, D + 1, zero3);
       if (threadIdx.x == 0) dsmall[(size_t)DPC_COL_DS * P.B + b] = 0.f;
     }
@@ -253,7 +254,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     }
   }
   DPC_STAMP(11);
-  if (blockIdx.x == 0 && !shared_points)
+  if (bk.x == 0 && !shared_points)
     for_each_record(cells, b, D, D + 1, [&](const PointRec&, const int4* aux) {
       const int i = aux->w;
       dcloud[3 * i + 0] = 0.f; dcloud[3 * i + 1] = 0.f; dcloud[3 * i + 2] = 0.f;
@@ -278,7 +279,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     if (t != nullptr)
       for (int i = 0; i < 3; ++i) atomicAdd(dtb + i, vals[9 + i]);
     if (f != nullptr) atomicAdd(dsmall + (size_t)DPC_COL_DF * P.B + b, vals[12]);
-    if (blockIdx.x == 0) {
+    if (bk.x == 0) {
       float ds = 0.f;
       for (int i = 0; i < n_ds_part; ++i) ds += ds_part[(size_t)b * n_ds_part + i];
       dsmall[(size_t)DPC_COL_DS * P.B + b] = ds * upstream;
@@ -305,7 +306,7 @@ int launch_gather_fast(const DpcParams* p, Cells cells, const float* pc, const f
     for (int c = 2; c <= 16; c *= 2)
       if (p->D % c == 0 && (size_t)(p->D / c) * p->B >= (size_t)kNumCUs) roll = c;
   const int nslab = (p->D + ZS - 1) / ZS;
-  DPC_LAUNCH("k_gather_hw", kern, dim3((nslab + roll - 1) / roll, p->B), dim3(Geo::NT), lds, st, *p, cells, pc, q, t, f,
+  DPC_LAUNCH("k_gather_hw", kern, dim3(((nslab + roll - 1) / roll) * p->B), dim3(Geo::NT), lds, st, *p, cells, pc, q, t, f,
              make_taps<RB>(kxy, pxy, true), ZS == 1 ? roll : ZS, dT, mask, ds_part, ntile, dpc, dsmall, la);
   return launch_ok();
 }
@@ -332,7 +333,7 @@ int launch_gather_rb(const DpcParams* p, Cells cells, const float* pc, const flo
   auto kern = k_gather_hw<0, 0, RB>;
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
-  DPC_LAUNCH("k_gather_hw", kern, dim3((p->D + Zs - 1) / Zs, p->B), dim3(slab_threads(p)), lds, st, *p, cells, pc, q, t, f,
+  DPC_LAUNCH("k_gather_hw", kern, dim3(((p->D + Zs - 1) / Zs) * p->B), dim3(slab_threads(p)), lds, st, *p, cells, pc, q, t, f,
              make_taps<RB>(kxy, pxy, true), Zs, dT, mask, ds_part, ntile, dpc, dsmall, la);
   return launch_ok();
 }

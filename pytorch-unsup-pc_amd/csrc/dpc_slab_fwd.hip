@@ -19,7 +19,8 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
                                                         const float* __restrict__ f, float* __restrict__ tr_pc,
                                                         uint8_t* __restrict__ cells_out) {
   __shared__ int hist[1026];  // D + 2 <= 1026 bins (validate() caps D at 1024)
-  const int b = blockIdx.y, blk = blockIdx.x, tid = threadIdx.x;
+  const Blk bk = block_coords(P.B);
+  const int b = bk.y, blk = bk.x, tid = threadIdx.x;
   const int D = P.D, nbins = D + 1;
   const int i = blk * kLocThreads + tid;
   const bool live = i < P.N;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
   }
   __syncthreads();
   const size_t chunk = chunk_bytes(D);
-  uint8_t* out = cells_out + ((size_t)b * gridDim.x + blk) * chunk;
+  uint8_t* out = cells_out + ((size_t)b * bk.nx + blk) * chunk;
   const int npts = min(kLocThreads, P.N - blk * kLocThreads);
   if (tid < npts) {
     reinterpret_cast<int4*>(out)[tid] = stage[tid];
@@ -113,16 +114,17 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
                                                            float* __restrict__ loss_zero, int* __restrict__ winner_zero,
                                                            unsigned long long* __restrict__ ticket_zero) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
-  if (sse != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {  // k_zcol_fwd accumulates into these
-    sse[blockIdx.y] = 0.f;
-    if (winner_zero != nullptr) winner_zero[blockIdx.y] = 0;   // K == 1: sample == cloud, candidate 0 wins
-    if (ticket_zero != nullptr) ticket_zero[blockIdx.y] = 0ull;  // k_zcol_fwdbwd's per-cloud sum-and-count word
-    if (ticket_zero != nullptr && blockIdx.y == 0) ticket_zero[gridDim.y] = 0ull;  // ... and the batch's, behind them
-    if (loss_zero != nullptr && blockIdx.y == 0) *loss_zero = 0.f;
+  const Blk bk = block_coords(P.B);
+  if (sse != nullptr && bk.x == 0 && threadIdx.x == 0) {  // k_zcol_fwd accumulates into these
+    sse[bk.y] = 0.f;
+    if (winner_zero != nullptr) winner_zero[bk.y] = 0;   // K == 1: sample == cloud, candidate 0 wins
+    if (ticket_zero != nullptr) ticket_zero[bk.y] = 0ull;  // k_zcol_fwdbwd's per-cloud sum-and-count word
+    if (ticket_zero != nullptr && bk.y == 0) ticket_zero[bk.ny] = 0ull;  // ... and the batch's, behind them
+    if (loss_zero != nullptr && bk.y == 0) *loss_zero = 0.f;
   }
   const int D = P.D, H = P.H, W = P.W;
   const int Zs = GS ? ZS : zs_rt;
-  const int b = blockIdx.y, z0 = blockIdx.x * Zs;
+  const int b = bk.y, z0 = bk.x * Zs;
   const int nz = min(Zs, D - z0);
   const int tid = threadIdx.x, nthr = blockDim.x;
   const size_t HW = (size_t)H * W;
@@ -331,7 +333,7 @@ int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const T
   auto kern = k_splat_hw<GS, ZS, RB>;
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
-  DPC_LAUNCH("k_splat_hw", kern, dim3((p->D + ZS - 1) / ZS, p->B), dim3(Geo::NT), lds, st, *p, cells,
+  DPC_LAUNCH("k_splat_hw", kern, dim3(((p->D + ZS - 1) / ZS) * p->B), dim3(Geo::NT), lds, st, *p, cells,
              make_taps<RB>(kxy, pxy, false), ZS, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
   return launch_ok();
 }
@@ -362,7 +364,7 @@ int launch_splat_rb(const DpcParams* p, Cells cells, const float* kxy, const Tap
   auto kern = k_splat_hw<0, 0, RB>;
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
-  DPC_LAUNCH("k_splat_hw", kern, dim3((p->D + Zs - 1) / Zs, p->B), dim3(slab_threads(p)), lds, st, *p, cells,
+  DPC_LAUNCH("k_splat_hw", kern, dim3(((p->D + Zs - 1) / Zs) * p->B), dim3(slab_threads(p)), lds, st, *p, cells,
              make_taps<RB>(kxy, pxy, false), Zs, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
   return launch_ok();
 }
@@ -381,7 +383,7 @@ int launch_splat(int bucket, const DpcParams* p, Cells cells, const float* kxy, 
 int launch_locate(const DpcParams* p, int src, const void* pts, const float* q, const float* t, const float* f,
                   float* tr_pc, void* cells, hipStream_t st) {
   if (p->N == 0 || p->B == 0) return DPC_OK;
-  dim3 g(num_chunks(p->N), p->B), blk(kLocThreads);
+  dim3 g(num_chunks(p->N) * p->B), blk(kLocThreads);
   uint8_t* out = static_cast<uint8_t*>(cells);
   if (src == 0) DPC_LAUNCH("k_locate", k_locate<0>, g, blk, 0, st, *p, pts, q, t, f, tr_pc, out);
   else if (src == 1) DPC_LAUNCH("k_locate", k_locate<1>, g, blk, 0, st, *p, pts, q, t, f, tr_pc, out);

@@ -52,6 +52,7 @@ class TrainStep:
         self.nets = StepNets(cfg).to(device)
         self.optimizer = torch.optim.Adam(self.nets.parameters(), lr=lr, weight_decay=cfg.weight_decay)  # train_to.py:73-74
         self.global_step = 0
+        self.grad_sync, self.sync_samples = None, (1, 1)
 
     def load_reference_state(self, state_dict):
         self.nets.load_state_dict(state_dict)
@@ -90,10 +91,17 @@ class TrainStep:
         return total, out
 
     def __call__(self, images, masks):
-        """zero_grad, forward, loss, backward, Adam step (train_to.py:112-131).  Returns the loss tensor (no host sync)."""
-        self.optimizer.zero_grad(set_to_none=True)
+        """zero_grad, forward, loss, backward, Adam step (train_to.py:112-131).  Returns the loss tensor (no host sync).
+        With `grad_sync` set (dpc.render.parallel.OverlappedGradAllReduce) the ranks' gradients are summed while the
+        backward runs; `sync_samples` = (objects of this rank, objects of all ranks)."""
+        if self.grad_sync is not None:
+            self.grad_sync.prepare(*self.sync_samples)
+        else:
+            self.optimizer.zero_grad(set_to_none=True)
         total, _ = self.loss(images, masks)
         total.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.finish()
         self.optimizer.step()
         self.global_step += 1
         return total.detach()

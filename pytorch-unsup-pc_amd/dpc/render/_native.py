@@ -10,7 +10,9 @@ import os
 import torch
 
 _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "csrc"))
-LIB_PATH = os.path.join(_CSRC, "libdpc_render.so")
+# DPC_RENDER_LIB points timing experiments at a variant build of the same library (tools/build_variant.sh); there is no
+# other implementation to fall back to either way
+LIB_PATH = os.environ.get("DPC_RENDER_LIB") or os.path.join(_CSRC, "libdpc_render.so")
 
 ABI_VERSION = 9
 DPC_MAX_TAPS = 63

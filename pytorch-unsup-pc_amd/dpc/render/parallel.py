@@ -8,6 +8,8 @@ gradients of the shared network parameters that sit above the renderer (encoder 
 chair_unsupervised).  xGMI is point-to-point (7 links x ~153 GB/s per GPU), so gradients are flattened into a
 few large buckets (one collective per bucket, all links busy) rather than one all-reduce per tensor.
 """
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -78,3 +80,147 @@ class BucketedGradAllReduce:
             for p in ps:
                 p.grad.copy_(flat[off:off + p.numel()].view_as(p.grad))
                 off += p.numel()
+
+
+class OverlappedGradAllReduce:
+    """The same exchange started from inside the backward ("bucketed and overlapped with the network
+    backward"; reference loop dpc/run/train_to.py:110-134 has a single process and no exchange at all).
+
+    Layout: parameters are packed into flat buckets of about `bucket_mb` in REVERSE registration order -- the order in
+    which autograd finishes their gradients, last layer first -- and every parameter's `.grad` is a VIEW into its
+    bucket, so nothing is packed or unpacked: autograd accumulates straight into the bucket.  A
+    post-accumulate-grad hook per parameter counts arrivals; the hook that completes a bucket scales it to the
+    rank's share of the global mean loss and starts its all-reduce asynchronously (RCCL runs it on its own stream,
+    ordered after the producing kernels), while autograd carries on with the layers below.  `finish()` starts the
+    buckets that never filled (parameters without gradient this step count as zeros, so every rank agrees on the
+    layout), waits for all of them and detaches the parameters that received no gradient (`.grad = None`, which is
+    what the single-process run hands the optimiser).
+
+        sync = OverlappedGradAllReduce(nets.parameters())
+        sync.prepare(local_samples, total_samples); loss.backward(); sync.finish(); optimizer.step()
+
+    xGMI is point-to-point and per-link bound: a few large buckets (default 32 MB) keep every link busy; a bucket per
+    tensor would pay one collective latency per layer.
+    """
+
+    def __init__(self, params, bucket_mb=32, group=None, overlap=True):
+        self.params = [p for p in params if p.requires_grad]
+        self.group, self.overlap = group, overlap
+        limit = max(1, int(bucket_mb * (1 << 20)) // 4)
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            size += p.numel()
+            if size >= limit:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self.flat, self.views, self._bucket_of = [], {}, {}
+        for bi, bucket in enumerate(self.buckets):
+            ref = bucket[0]
+            flat = torch.zeros(sum(p.numel() for p in bucket), dtype=ref.dtype, device=ref.device)
+            off = 0
+            for p in bucket:
+                if p.dtype != ref.dtype or p.device != ref.device:
+                    raise ValueError("parameters of one exchange must share dtype and device")
+                self.views[id(p)] = flat[off:off + p.numel()].view_as(p)
+                self._bucket_of[id(p)] = bi
+                off += p.numel()
+            self.flat.append(flat)
+        self.num_buckets = len(self.buckets)
+        self.nbytes = sum(f.numel() * f.element_size() for f in self.flat)
+        self._expected = [len(b) for b in self.buckets]   # arrivals that complete a bucket; adapts after the first step
+        self._arrived = [0] * self.num_buckets
+        self._seen = set()
+        self._work = [None] * self.num_buckets
+        self._scale, self._armed = 1.0, False
+        self._events, self._host_exposed, self.steps = [], 0.0, 0
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+
+    def _active(self):
+        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def prepare(self, local_samples, total_samples):
+        """Before the backward: zero the buckets, point every .grad at its slice, reset the arrival counters."""
+        self._scale = float(local_samples) / float(total_samples)   # local mean -> contribution to the global mean
+        for flat in self.flat:
+            flat.zero_()
+        for p in self.params:
+            p.grad = self.views[id(p)]
+        self._arrived = [0] * self.num_buckets
+        self._seen.clear()
+        self._work = [None] * self.num_buckets
+        self._armed = True
+
+    def _launch(self, bi):
+        flat = self.flat[bi]
+        if self._scale != 1.0:
+            flat.mul_(self._scale)
+        if self._active():
+            self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            self._work[bi] = True
+
+    def _hook(self, p):
+        if not self._armed:
+            return
+        bi, view = self._bucket_of[id(p)], self.views[id(p)]
+        if p.grad.data_ptr() != view.data_ptr():   # autograd replaced the view (it does when .grad was None)
+            view.copy_(p.grad)
+            p.grad = view
+        if self._work[bi] is not None:
+            raise RuntimeError("a gradient arrived after its bucket had been sent (the set of parameters with a gradient "
+                               "changed between steps)")
+        self._seen.add(id(p))
+        self._arrived[bi] += 1
+        if self.overlap and self._arrived[bi] == self._expected[bi]:
+            self._launch(bi)
+
+    def finish(self):
+        """After the backward: send what is left, wait, drop the gradients nothing contributed to."""
+        for bi in range(self.num_buckets):
+            if self._work[bi] is None:
+                self._launch(bi)
+        on_gpu = self.flat[0].is_cuda
+        if on_gpu:   # how long the compute stream stalls on the collectives = the part of the exchange NOT hidden
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        else:
+            t0 = time.perf_counter()
+        for w in self._work:
+            if w is not True:
+                w.wait()
+        if on_gpu:
+            ev[1].record()
+            self._events.append(ev)
+        else:
+            self._host_exposed += time.perf_counter() - t0
+        self.steps += 1
+        # buckets fill only as far as gradients really arrive: learn that from this step (same on every rank, the
+        # graphs are the same), so that from the next step on every bucket goes out the moment its last gradient lands
+        self._expected = [a if a > 0 else len(b) for a, b in zip(self._arrived, self.buckets)]
+        for p in self.params:
+            if id(p) not in self._seen:
+                p.grad = None
+        self._armed = False
+
+    @property
+    def exposed_seconds(self):
+        """Total time the compute stream (GPU) or the host (CPU tensors) waited for collectives in finish()."""
+        if self._events:
+            self._events[-1][1].synchronize()
+        return self._host_exposed + 1e-3 * sum(a.elapsed_time(b) for a, b in self._events)
+
+    def exchange_only(self):
+        """The collectives alone on the current bucket contents (timing aid)."""
+        if not self._active():
+            return
+        works = [dist.all_reduce(f, op=dist.ReduceOp.SUM, group=self.group, async_op=True) for f in self.flat]
+        for w in works:
+            w.wait()
+
+    def remove(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []

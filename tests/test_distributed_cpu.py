@@ -148,3 +148,49 @@ def test_two_rank_gradients_of_the_real_networks():
                 assert float(g.abs().max()) == 0.0, k  # zero-filled, took part in the exchange
             else:
                 assert torch.allclose(g, p.grad, rtol=1e-4, atol=1e-6 * float(p.grad.abs().max())), k
+
+
+# ------------------------------------------------------------------------------------------------------
+# The exchange started from autograd hooks while the backward is still running (what bench.py --config c3 runs over
+# RCCL): two steps, so that the second one goes through the adapted per-bucket arrival counts.
+# ------------------------------------------------------------------------------------------------------
+def _hooked_worker(rank, world, port, ret):
+    from dpc.render.parallel import OverlappedGradAllReduce, shard_samples
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        cfg, nets, images, gt = _harness_problem()
+        lo, hi = shard_samples(cfg.batch_size, rank, world)
+        sync = OverlappedGradAllReduce(nets.parameters(), bucket_mb=0.05)
+        launched_early = []
+        for _ in range(2):
+            sync.prepare((hi - lo) * cfg.step_size, cfg.batch_size * cfg.step_size)
+            _harness_loss(cfg, nets, images, gt, lo, hi).backward()
+            launched_early.append(sum(w is not None for w in sync._work))   # buckets already on the wire before finish()
+            sync.finish()
+        ret[rank] = dict(grads={k: (None if p.grad is None else p.grad.clone()) for k, p in nets.named_parameters()},
+                         early=launched_early, buckets=sync.num_buckets)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_exchange_matches_single_process():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_hooked_worker, args=(2, port, ret), nprocs=2, join=True)
+    cfg, nets, images, gt = _harness_problem()
+    _harness_loss(cfg, nets, images, gt, 0, cfg.batch_size).backward()
+    for r in (0, 1):
+        assert ret[r]["buckets"] > 3
+        # first step: buckets holding a gradient-less parameter wait for finish(); second step: every bucket that gets
+        # any gradient is sent from inside the backward
+        assert ret[r]["early"][1] >= ret[r]["early"][0] > 0
+        for k, p in nets.named_parameters():
+            g = ret[r]["grads"][k]
+            if p.grad is None:
+                assert g is None, k   # the optimiser sees what the single-process run shows it
+            else:
+                assert torch.allclose(g, p.grad, rtol=1e-4, atol=1e-6 * float(p.grad.abs().max())), k

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Per-phase timeline of the slab kernels from a -DDPC_ABLATE build (tools/build_variant.sh abl -DDPC_ABLATE):
+   DPC_RENDER_LIB=scratch/abl/libdpc_render.so python tools/stamps.py [c2|c4]
+Stamps are 100 MHz s_memrealtime values written by thread 0 of every workgroup (diagnostic build only)."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "pytorch-unsup-pc_amd"))
+import numpy as np
+import torch
+
+import dpc.render as R
+from dpc.harness import chair_unsupervised
+from dpc.render import _native
+import bench
+
+cfgname = sys.argv[1] if len(sys.argv) > 1 else "c2"
+B, N, G, SIG, K = bench.CONFIGS[cfgname]
+cfg = chair_unsupervised(vox_size=G, pc_gauss_kernel_size=21)
+kern = R.smoothing_kernel(cfg, SIG)
+pc, q, s, gt = [x.cuda().float() for x in bench.synthetic_inputs(B, N, G, 1234)]
+pc.requires_grad_(True), q.requires_grad_(True), s.requires_grad_(True)
+L = _native.lib()
+L.dpc_debug_set_stamps.argtypes = [ctypes.c_void_p]
+
+
+def step():
+    pc.grad = q.grad = s.grad = None
+    loss, _, _ = R.pointcloud_project_loss(cfg, pc, q, None, None, kern, scaling_factor=s, gt=gt)
+    loss.backward()
+
+
+for _ in range(5):
+    step()
+NB = 64 * B
+buf = torch.zeros(NB * 16, dtype=torch.int64, device="cuda")
+torch.cuda.synchronize()
+L.dpc_debug_set_stamps(ctypes.c_void_p(buf.data_ptr()))
+step()
+torch.cuda.synchronize()
+L.dpc_debug_set_stamps(None)
+st = buf.cpu().numpy().reshape(-1, 16).astype(np.float64) * 0.01  # us
+
+
+def report(name, slots, labels):
+    rows = st[(st[:, slots[0]] > 0) & (st[:, slots[-1]] > 0)]
+    if not len(rows):
+        print(name, ": no stamps")
+        return
+    a = rows[:, slots]
+    t0 = a[:, 0].min()
+    start, end = a[:, 0] - t0, a[:, -1] - t0
+    dur = a[:, -1] - a[:, 0]
+    print("%s: %d workgroups; last start %.2f us, span %.2f us, WG duration mean %.2f (min %.2f max %.2f)"
+          % (name, len(rows), start.max(), end.max(), dur.mean(), dur.min(), dur.max()))
+    d = np.diff(a, axis=1)
+    for l, m, mx in zip(labels, d.mean(0), d.max(0)):
+        print("    %-28s mean %6.2f us   max %6.2f" % (l, m, mx))
+    print("    start deciles", np.round(np.percentile(start, [0, 10, 25, 50, 75, 90, 100]), 2),
+          " end deciles", np.round(np.percentile(end, [0, 10, 25, 50, 75, 90, 100]), 2))
+
+
+report("k_splat_hw", [0, 1, 2, 3, 4, 5], ["zero+table", "scatter", "W-load/convert", "W-compute/write", "H-pass+store"])
+report("k_gather_hw", [8, 9, 11, 12, 13], ["pads+H-pass(global)", "gather", "block_sum", "epilogue"])
