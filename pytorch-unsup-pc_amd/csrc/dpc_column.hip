@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kColThreads, (RPL * DD <= 128 ? 2 : 1))
 void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, const float* __restrict__ s, TapsT<RB> taps,
                    TapsT<RB> taps_adj, float* __restrict__ proj, float* __restrict__ dT, float* __restrict__ ds_part,
                    int n_ds_part, unsigned long long* __restrict__ tickets, int batch_frac, float* __restrict__ dsmall,
-                   LossArgs la) {
+                   unsigned int* __restrict__ cg_count, LossArgs la) {
   typedef float vec __attribute__((ext_vector_type(RPL)));
   const int HW = P.H * P.W;
   const Blk bk = block_coords(P.B);
@@ -276,6 +276,7 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
     }
   }
   if (bk.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)threadIdx.x * bk.ny + b] = 0.f;  // [col][B]
+  if (bk.x == 0 && threadIdx.x == 0) cg_count[b] = 0u;  // k_gather_hw's arrival counter of this cloud
 }
 
 // Generic depth / tap count: same arithmetic, column re-read from global (L1/L2 serve the re-reads).
@@ -329,7 +330,7 @@ __device__ inline float ray_grad(const DpcParams& P, const LossArgs& la, const f
   return 2.0f * la.inv_S * up * (proj[(size_t)b * HW + pix] - la.gt[(size_t)(b / la.K) * HW + pix]);
 }
 
-__device__ inline void zcol_bwd_epilogue(float ds_acc, float* ds_part, float* dsmall, const Blk& bk) {
+__device__ inline void zcol_bwd_epilogue(float ds_acc, float* ds_part, float* dsmall, unsigned int* cg_count, const Blk& bk) {
   const int b = bk.y;
   __shared__ float red[kColThreads / DPC_WAVE];
   const float w = wave_sum(ds_acc);
@@ -341,6 +342,7 @@ __device__ inline void zcol_bwd_epilogue(float ds_acc, float* ds_part, float* ds
     ds_part[(size_t)b * bk.nx + bk.x] = tot;
   }
   if (bk.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)threadIdx.x * bk.ny + b] = 0.f;  // [col][B]
+  if (bk.x == 0 && threadIdx.x == 0) cg_count[b] = 0u;  // k_gather_hw's arrival counter of this cloud
 }
 
 // Reads the grid saved by the forward slab kernel (after clamp + W/H passes), recomputes the forward D-pass in
@@ -353,7 +355,8 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
                                                           const float* __restrict__ trans_in, TapsT<RB> taps,
                                                           TapsT<RB> taps_adj,
                                                           float* __restrict__ dT, float* __restrict__ ds_part,
-                                                          float* __restrict__ dsmall, LossArgs la) {
+                                                          float* __restrict__ dsmall, unsigned int* __restrict__ cg_count,
+                                                          LossArgs la) {
   const int HW = P.H * P.W;
   const Blk bk = block_coords(P.B);
   const int b = bk.y, ray = bk.x * kColThreads + threadIdx.x;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
       if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   }
-  zcol_bwd_epilogue(ds_acc, ds_part, dsmall, bk);
+  zcol_bwd_epilogue(ds_acc, ds_part, dsmall, cg_count, bk);
 }
 
 __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHost rh, const float* __restrict__ Tin,
@@ -421,7 +424,8 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHo
                                                               const float* __restrict__ trans_in, TapsDyn taps,
                                                               TapsDyn taps_adj,
                                                               float* __restrict__ dT, float* __restrict__ ds_part,
-                                                              float* __restrict__ dsmall, LossArgs la) {
+                                                              float* __restrict__ dsmall, unsigned int* __restrict__ cg_count,
+                                                              LossArgs la) {
   const int HW = P.H * P.W, D = P.D;
   const Blk bk = block_coords(P.B);
   const int b = bk.y, ray = bk.x * kColThreads + threadIdx.x;
@@ -469,14 +473,14 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHo
       out[(size_t)z * HW] = acc;
     }
   }
-  zcol_bwd_epilogue(ds_acc, ds_part, dsmall, bk);
+  zcol_bwd_epilogue(ds_acc, ds_part, dsmall, cg_count, bk);
 }
 
 }  // namespace
 
 int launch_zcol_fwdbwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* Tbuf, const float* s,
                        float* proj, float* dT, float* ds_part, int ntile, unsigned long long* tickets, float* bwd_dsmall,
-                       const LossArgs& la, hipStream_t st) {
+                       unsigned int* cg_count, const LossArgs& la, hipStream_t st) {
   int rc = DPC_OK;
   const RayHost rh = ray_host(p);
   constexpr int kRpl = DPC_ZFB_RPL;
@@ -488,9 +492,9 @@ int launch_zcol_fwdbwd(const DpcParams* p, const float* host_kern_z, const TapPl
 #define DPC_ZFB(RB)                                                                                                \
   {                                                                                                                \
     const TapsT<RB> tzf = make_taps<RB>(host_kern_z, pz, false), tza = make_taps<RB>(host_kern_z, pz, true);       \
-    if (p->D == 32) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<32, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, batch_frac, bwd_dsmall, la); \
-    else if (p->D == 64) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<64, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, batch_frac, bwd_dsmall, la); \
-    else DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<128, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, batch_frac, bwd_dsmall, la); \
+    if (p->D == 32) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<32, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, batch_frac, bwd_dsmall, cg_count, la); \
+    else if (p->D == 64) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<64, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, batch_frac, bwd_dsmall, cg_count, la); \
+    else DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<128, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, batch_frac, bwd_dsmall, cg_count, la); \
   }
   DPC_FOR_BUCKET(pz.bucket, DPC_ZFB)
 #undef DPC_ZFB
@@ -522,7 +526,7 @@ int launch_zcol_fwd(const DpcParams* p, const float* host_kern_z, const TapPlan&
 
 int launch_zcol_bwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* grid_wh, const float* s,
                     const float* dproj, const float* proj, const float* trans, float* dT, float* ds_part, float* dsmall,
-                    const LossArgs& la, hipStream_t st) {
+                    unsigned int* cg_count, const LossArgs& la, hipStream_t st) {
   int rc = DPC_OK;
   const RayHost rh = ray_host(p);
   dim3 gcol(col_tiles(p) * p->B);
@@ -530,9 +534,9 @@ int launch_zcol_bwd(const DpcParams* p, const float* host_kern_z, const TapPlan&
 #define DPC_ZBWD(RB)                                                                                              \
   {                                                                                                               \
     const TapsT<RB> tz = make_taps<RB>(host_kern_z, pz, true), tzf = make_taps<RB>(host_kern_z, pz, false);       \
-    if (p->D == 32) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, la); done = true; } \
-    else if (p->D == 64) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, la); done = true; } \
-    else if (p->D == 128) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, la); done = true; } \
+    if (p->D == 32) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, cg_count, la); done = true; } \
+    else if (p->D == 64) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, cg_count, la); done = true; } \
+    else if (p->D == 128) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, cg_count, la); done = true; } \
   }
   if (pz.bucket >= 0) { DPC_FOR_BUCKET(pz.bucket, DPC_ZBWD) }
 #undef DPC_ZBWD
@@ -540,7 +544,7 @@ int launch_zcol_bwd(const DpcParams* p, const float* host_kern_z, const TapPlan&
   if (!done) {
     DPC_LAUNCH("k_zcol_bwd", k_zcol_bwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans,
                make_taps_dyn(host_kern_z, p->taps_z, false), make_taps_dyn(host_kern_z, p->taps_z, true), dT, ds_part,
-               dsmall, la);
+               dsmall, cg_count, la);
   }
   return launch_ok();
 }

@@ -353,3 +353,50 @@ __device__ inline void block_sum(float (&vals)[NV], float* red) {
     for (int i = 0; i < NV; ++i) vals[i] = __shfl(s, i, DPC_WAVE);
   }
 }
+
+// Fixed-order fp64 block sum of the 13 camera-gradient accumulators and d(q) in fp64: see the notes on the camera
+// gradient in dpc_kernels.h.  scratch: camgrad_scratch_bytes(nthr) of LDS nobody else is using.
+__host__ __device__ constexpr size_t camgrad_scratch_bytes(int nthr) { return (size_t)13 * (nthr / DPC_WAVE) * sizeof(float); }
+
+// nthr a multiple of 64.  Per wave a DPP butterfly (a fixed tree, fp32: the per-point values are fp32 and their rounding
+// dominates the error, measured); the wave totals go through LDS and lanes 0..12 of the first wave add them in wave order
+// in fp64.  The order of every addition is fixed by the thread ids alone.  Returns value `tid`'s total in threads 0..12.
+// (A version that parked all 13 x nthr values in LDS and summed them in fp64 measured 0.7 us slower per workgroup and no
+// more accurate.)
+__device__ inline double block_sum13_fixed(const float (&vals)[13], float* scratch, int tid, int nthr) {
+  const int lane = tid & (DPC_WAVE - 1), wave = tid / DPC_WAVE, nw = nthr / DPC_WAVE;
+  float ws[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) ws[i] = wave_sum(vals[i]);
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 13; ++i) scratch[wave * 13 + i] = ws[i];
+  }
+  __syncthreads();
+  double tot = 0.0;
+  if (tid < 13)
+    for (int k = 0; k < nw; ++k) tot += (double)scratch[k * 13 + tid];
+  return tot;
+}
+
+// d(q) from the moment matrix in fp64 (same algebra as quaternion_grad)
+__device__ inline void quaternion_grad_f64(const float* q_raw, const double* m, double* dq) {
+  double w = q_raw[0], vx = q_raw[1], vy = q_raw[2], vz = q_raw[3];
+  const double inv_norm = 1.0 / sqrt(w * w + vx * vx + vy * vy + vz * vz);
+  w *= inv_norm; vx *= inv_norm; vy *= inv_norm; vz *= inv_norm;
+  const double tr = m[0] + m[4] + m[8];
+  const double cx = m[5] - m[7], cy = m[6] - m[2], cz = m[1] - m[3];
+  const double sx = 2.0 * m[0] * vx + (m[1] + m[3]) * vy + (m[2] + m[6]) * vz;
+  const double sy = (m[3] + m[1]) * vx + 2.0 * m[4] * vy + (m[5] + m[7]) * vz;
+  const double sz = (m[6] + m[2]) * vx + (m[7] + m[5]) * vy + 2.0 * m[8] * vz;
+  const double gw = 2.0 * (w * tr + vx * cx + vy * cy + vz * cz);
+  const double gx = 2.0 * (-tr * vx + sx + w * cx);
+  const double gy = 2.0 * (-tr * vy + sy + w * cy);
+  const double gz = 2.0 * (-tr * vz + sz + w * cz);
+  const double dot = w * gw + vx * gx + vy * gy + vz * gz;
+  dq[0] = (gw - w * dot) * inv_norm;
+  dq[1] = (gx - vx * dot) * inv_norm;
+  dq[2] = (gy - vy * dot) * inv_norm;
+  dq[3] = (gz - vz * dot) * inv_norm;
+}
+

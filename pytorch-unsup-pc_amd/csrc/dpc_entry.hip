@@ -7,10 +7,10 @@
 using namespace dpck;
 
 #ifdef DPC_ABLATE
-extern "C" int dpc_debug_set_ablate_fwd(int), dpc_debug_set_ablate_col(int), dpc_debug_set_ablate_bwd(int);
-extern "C" int dpc_debug_set_stamps_fwd(void*), dpc_debug_set_stamps_col(void*), dpc_debug_set_stamps_bwd(void*);
-extern "C" int dpc_debug_set_ablate(int v) { return dpc_debug_set_ablate_fwd(v) | dpc_debug_set_ablate_col(v) | dpc_debug_set_ablate_bwd(v); }
-extern "C" int dpc_debug_set_stamps(void* p) { return dpc_debug_set_stamps_fwd(p) | dpc_debug_set_stamps_col(p) | dpc_debug_set_stamps_bwd(p); }
+extern "C" int dpc_debug_set_ablate_fwd(int), dpc_debug_set_ablate_col(int), dpc_debug_set_ablate_bwd(int), dpc_debug_set_ablate_xl(int);
+extern "C" int dpc_debug_set_stamps_fwd(void*), dpc_debug_set_stamps_col(void*), dpc_debug_set_stamps_bwd(void*), dpc_debug_set_stamps_xl(void*);
+extern "C" int dpc_debug_set_ablate(int v) { return dpc_debug_set_ablate_fwd(v) | dpc_debug_set_ablate_col(v) | dpc_debug_set_ablate_bwd(v) | dpc_debug_set_ablate_xl(v); }
+extern "C" int dpc_debug_set_stamps(void* p) { return dpc_debug_set_stamps_fwd(p) | dpc_debug_set_stamps_col(p) | dpc_debug_set_stamps_bwd(p) | dpc_debug_set_stamps_xl(p); }
 #endif
 
 extern "C" {
@@ -24,9 +24,7 @@ size_t dpc_cells_bytes(const DpcParams* p) {
 
 size_t dpc_workspace_bytes(const DpcParams* p) {
   if (validate(p) != DPC_OK) return 0;
-  const size_t grid = (size_t)p->B * p->D * p->H * p->W * sizeof(float);
-  const size_t parts = (size_t)p->B * col_tiles(p) * sizeof(float) + ((size_t)p->B + 1) * 8 + 8;  // ds partials; 8-byte aligned sum-and-count words (clouds + batch)
-  return ((grid + 255) / 256) * 256 + ((parts + 255) / 256) * 256;
+  return ws_total_bytes(p);   // layout: workspace_view() in dpc_kernels.h
 }
 
 int dpc_locate(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, float* tr_pc,
@@ -83,16 +81,15 @@ int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const 
   // backward; its per-cloud sum-and-count words live behind the ds partials and are zeroed by the slab kernel
   const bool fuse_bwd = bwd_workspace != nullptr && bwd_dsmall != nullptr && la.loss_direct != nullptr &&
                         can_fuse_column_backward(p, pz, la.K, Tbuf, proj, la.gt, bwd_workspace);
-  const size_t grid_bytes = (((size_t)p->B * p->D * p->H * p->W * sizeof(float) + 255) / 256) * 256;
-  float* ds_part = fuse_bwd ? reinterpret_cast<float*>(static_cast<char*>(bwd_workspace) + grid_bytes) : nullptr;
-  unsigned long long* tickets = nullptr;  // B per-cloud words + 1 batch word behind the ds partials, 8-byte aligned
-  if (fuse_bwd)
-    tickets = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(ds_part + (size_t)p->B * col_tiles(p)) + 7u) & ~(uintptr_t)7u);
+  Workspace w{nullptr, nullptr, nullptr, nullptr, nullptr};
+  if (fuse_bwd) w = workspace_view(p, bwd_workspace);
+  float* ds_part = w.ds_part;
+  unsigned long long* tickets = w.tickets;  // B per-cloud words + 1 batch word behind the ds partials, 8-byte aligned
   if ((rc = launch_splat(pxy.bucket, p, cv, host_kern_xy, pxy, raw, Tbuf, mask, la.sse, la.loss_direct, la.winner_out, tickets, st)) != DPC_OK)
     return rc;
   if (fuse_bwd)
-    return launch_zcol_fwdbwd(p, host_kern_z, pz, Tbuf, s, proj, static_cast<float*>(bwd_workspace), ds_part, col_tiles(p),
-                              tickets, bwd_dsmall, la, st);
+    return launch_zcol_fwdbwd(p, host_kern_z, pz, Tbuf, s, proj, w.dT, ds_part, col_tiles(p), tickets, bwd_dsmall, w.cg_count,
+                              la, st);
   return launch_zcol_fwd(p, host_kern_z, pz, Tbuf, s, smoothed, proj, trans, la, st);
 }
 
@@ -110,15 +107,13 @@ int project_bwd_impl(const DpcParams* p, const float* pc, const float* q, const 
   if (p->B == 0) return DPC_OK;
   const TapPlan pxy = plan_taps(host_kern_xy, p->taps_xy), pz = plan_taps(host_kern_z, p->taps_z);
   if (pxy.bucket < 0) return DPC_ERR_TAPS;
-  float* dT = static_cast<float*>(workspace);
-  const size_t grid_bytes = (((size_t)p->B * p->D * p->H * p->W * sizeof(float) + 255) / 256) * 256;
-  float* ds_part = reinterpret_cast<float*>(static_cast<char*>(workspace) + grid_bytes);
+  const Workspace w = workspace_view(p, workspace);
   const int ntile = col_tiles(p);
   if (!column_done &&
-      (rc = launch_zcol_bwd(p, host_kern_z, pz, grid_wh, s, dproj, proj, trans, dT, ds_part, dsmall, la, st)) != DPC_OK)
+      (rc = launch_zcol_bwd(p, host_kern_z, pz, grid_wh, s, dproj, proj, trans, w.dT, w.ds_part, dsmall, w.cg_count, la, st)) != DPC_OK)
     return rc;
-  return launch_gather(pxy.bucket, p, cells_view(p, cells), pc, q, t, f, host_kern_xy, pxy, dT, mask, ds_part, ntile, dpc, dsmall,
-                       la, st);
+  return launch_gather(pxy.bucket, p, cells_view(p, cells), pc, q, t, f, host_kern_xy, pxy, w.dT, mask, w.ds_part, ntile, dpc,
+                       dsmall, w.cg_part, w.cg_count, la, st);
 }
 
 const LossArgs kNoLoss{nullptr, nullptr, nullptr, nullptr, 1, 1.0f, nullptr, nullptr, 0};

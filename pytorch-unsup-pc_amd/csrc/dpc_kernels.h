@@ -623,6 +623,95 @@ __device__ inline bool cloud_loses(const LossArgs& la, int b) {
   return la.gt != nullptr && la.winner[b / la.K] != b % la.K;
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Backward workspace (dpc_workspace_bytes): [dT grid][ds partials B x ntile][sum-and-count words B + 1]
+//                                           [camera-gradient partials B x D x 16 doubles][arrival counters B]
+// ------------------------------------------------------------------------------------------------------
+struct Workspace {
+  float* dT;
+  float* ds_part;
+  unsigned long long* tickets;   // k_zcol_fwdbwd: per-cloud squared-error words + the batch word
+  double* cg_part;               // k_gather_hw: per-slab sums of the 13 camera-gradient accumulators
+  unsigned int* cg_count;        // k_gather_hw: slabs of a cloud that have published (zeroed by the column kernels)
+};
+inline size_t ws_round(size_t n) { return (n + 255) / 256 * 256; }
+inline size_t ws_grid_bytes(const DpcParams* p) { return ws_round((size_t)p->B * p->D * p->H * p->W * sizeof(float)); }
+inline size_t ws_parts_bytes(const DpcParams* p) {
+  return ws_round((size_t)p->B * col_tiles(p) * sizeof(float) + ((size_t)p->B + 1) * 8 + 8);
+}
+inline size_t ws_camgrad_bytes(const DpcParams* p) { return ws_round((size_t)p->B * p->D * 16 * sizeof(double)); }
+inline size_t ws_total_bytes(const DpcParams* p) {
+  return ws_grid_bytes(p) + ws_parts_bytes(p) + ws_camgrad_bytes(p) + ws_round((size_t)p->B * sizeof(unsigned int));
+}
+inline Workspace workspace_view(const DpcParams* p, void* ws) {
+  Workspace w;
+  char* base = static_cast<char*>(ws);
+  w.dT = reinterpret_cast<float*>(base);
+  w.ds_part = reinterpret_cast<float*>(base + ws_grid_bytes(p));
+  w.tickets = reinterpret_cast<unsigned long long*>(
+      (reinterpret_cast<uintptr_t>(w.ds_part + (size_t)p->B * col_tiles(p)) + 7u) & ~(uintptr_t)7u);
+  w.cg_part = reinterpret_cast<double*>(base + ws_grid_bytes(p) + ws_parts_bytes(p));
+  w.cg_count = reinterpret_cast<unsigned int*>(base + ws_grid_bytes(p) + ws_parts_bytes(p) + ws_camgrad_bytes(p));
+  return w;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Camera gradient of a cloud (dq, dt, df): 13 sums over the cloud's points, taken in a FIXED order so that the result
+// is the same bits on every run (float atomics between the slab workgroups made dq/dt/df vary in the last places), and in
+// fp64 from the per-thread values on (the fp32 tree it replaces cost a third of the d(q) parity margin).
+//   block_sum13_fixed  every thread parks its 13 values in LDS, value-major; 13 x 16 threads each add a stride-16 comb
+//                      of one value (the lanes of a comb group read consecutive words: conflict-free); 13 threads add
+//                      the 16 comb sums.  Also ~4x cheaper than 13 DPP wave reductions + the cross-wave pass.
+//   camgrad_publish    the slab workgroups of a cloud hand their sums over INSIDE the launch: write-through (sc1) stores
+//                      of the 13 doubles, the storing wave's vmcnt(0), one agent-scope ticket add; the workgroup that
+//                      drew the last ticket reads all slabs' sums with sc1 loads in slab order, turns the moment matrix
+//                      into d(q) in fp64 and writes dq/dt/df.  This is the hand-off form MI355X_MICROARCH.md lists as
+//                      measured valid on gfx950 ("Valid forms", first table row: one lane's agent-scope add as the signal,
+//                      the last adder told by the returned value, all handed-off bytes stored and loaded sc1); no L2
+//                      write-back, no acquire.  The counter is left at zero again for the next backward.
+// scratch: 13 * nthr floats + 208 doubles of LDS nobody else is using (callers pass the dead slab, behind a barrier).
+// ------------------------------------------------------------------------------------------------------
+// tot: this slab's sum of accumulator `tid` (threads 0..12, from block_sum13_fixed).  Called by the whole first wave.
+__device__ inline void camgrad_publish(double tot, int tid, const CameraRaw& raw, int B, int b, int slab, int nslab,
+                                       double* __restrict__ cg_part, unsigned int* __restrict__ cg_count,
+                                       float* __restrict__ dsmall, bool has_t, bool has_f) {
+  if (tid >= DPC_WAVE) return;
+  unsigned long long* mine = reinterpret_cast<unsigned long long*>(cg_part + ((size_t)b * nslab + slab) * 16);
+  if (tid < 13) __hip_atomic_store(mine + tid, (unsigned long long)__double_as_longlong(tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the stores have left this wave before the ticket is drawn
+  unsigned int ticket = 0;
+  if (tid == 0) ticket = __hip_atomic_fetch_add(cg_count + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+  if (ticket != (unsigned int)(nslab - 1)) return;   // somebody else arrives later and does the sum
+  double sum = 0.0;
+  if (tid < 13) {
+    const unsigned long long* all = reinterpret_cast<const unsigned long long*>(cg_part + (size_t)b * nslab * 16);
+    for (int k0 = 0; k0 < nslab; k0 += 8) {   // slab order: the same sum on every run; eight loads in flight at a time
+      unsigned long long raw[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        raw[u] = __hip_atomic_load(all + (size_t)min(k0 + u, nslab - 1) * 16 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (k0 + u < nslab) sum += __longlong_as_double((long long)raw[u]);
+    }
+  }
+  double m[13];
+#pragma unroll
+  for (int i = 0; i < 13; ++i) m[i] = __shfl(sum, i, DPC_WAVE);
+  if (tid == 0) {
+    double dq[4];
+    quaternion_grad_f64(raw.q, m, dq);
+    float* dqb = dsmall + (size_t)DPC_COL_DQ * B + (size_t)b * 4;   // dq as a [B,4] block, dt [B,3], df [B,1] (dpc_render.h)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dqb[i] = (float)dq[i];
+    if (has_t)
+      for (int i = 0; i < 3; ++i) dsmall[(size_t)DPC_COL_DT * B + (size_t)b * 3 + i] = (float)m[9 + i];
+    if (has_f) dsmall[(size_t)DPC_COL_DF * B + b] = (float)m[12];
+    __hip_atomic_store(cg_count + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next backward
+  }
+}
+
 // ---- launchers defined next to their kernels (bucket = compile-time tap radius bucket chosen by plan_taps) ----
 int launch_locate(const DpcParams* p, int src, const void* pts, const float* q, const float* t, const float* f, float* tr_pc,
                   void* cells, hipStream_t st);
@@ -630,15 +719,22 @@ int launch_splat(int bucket, const DpcParams* p, Cells cells, const float* kxy, 
                  uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st);
 int launch_gather(int bucket, const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
                   const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part, int ntile,
-                  float* dpc, float* dsmall, const LossArgs& la, hipStream_t st);
+                  float* dpc, float* dsmall, double* cg_part, unsigned int* cg_count, const LossArgs& la, hipStream_t st);
 int launch_zcol_fwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* Tbuf, const float* s,
                     float* smoothed, float* proj, float* trans, const LossArgs& la, hipStream_t st);
 int launch_zcol_fwdbwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* Tbuf, const float* s,
                        float* proj, float* dT, float* ds_part, int ntile, unsigned long long* tickets, float* bwd_dsmall,
-                       const LossArgs& la, hipStream_t st);
+                       unsigned int* cg_count, const LossArgs& la, hipStream_t st);
 int launch_zcol_bwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* grid_wh, const float* s,
                     const float* dproj, const float* proj, const float* trans, float* dT, float* ds_part, float* dsmall,
-                    const LossArgs& la, hipStream_t st);
+                    unsigned int* cg_count, const LossArgs& la, hipStream_t st);
 int launch_loss_finalize(const float* sse, int S, int K, float inv_S, float* loss, int32_t* winner, hipStream_t st);
+// dpc_slab_xl.hip: the x-in-lanes slab kernels (64 x 64 planes, radius bucket 1..6); DPC_NO_XL builds keep the older kernels
+bool xl_applies(const DpcParams* p, int bucket);
+int launch_splat_xl(int bucket, const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* Tbuf, uint64_t* mask,
+                    float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st);
+int launch_gather_xl(int bucket, const DpcParams* p, Cells cells, const float* q, const float* t, const float* f, const float* kxy,
+                     const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part, int ntile, float* dpc,
+                     float* dsmall, double* cg_part, unsigned int* cg_count, const LossArgs& la, hipStream_t st);
 
 }  // namespace dpck

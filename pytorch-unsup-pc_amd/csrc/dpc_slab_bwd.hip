@@ -19,7 +19,8 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
                                                             const uint64_t* __restrict__ mask,
                                                             const float* __restrict__ ds_part, int n_ds_part,
                                                             float* __restrict__ dpc, float* __restrict__ dsmall,
-                                                            LossArgs la) {
+                                                            double* __restrict__ cg_part,
+                                                            unsigned int* __restrict__ cg_count, LossArgs la) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
   const int D = P.D, H = P.H, W = P.W, N = P.N, HW = H * W;
   const int Zs = GS ? ZS : zs_rt;
@@ -265,33 +266,22 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   for (int i = 0; i < 9; ++i) vals[i] = g.m[i];
   vals[9] = g.dt[0]; vals[10] = g.dt[1]; vals[11] = g.dt[2]; vals[12] = g.df;
   if (DPC_ABL(13)) { if (vals[0] == 123.f) dsmall[0] = vals[1]; return; }
-  block_sum<13>(vals, red);
+  const double tot = block_sum13_fixed(vals, red, tid, nthr);
   DPC_STAMP(12);
-  if (DPC_ABL(14)) { if (vals[0] == 123.f) dsmall[0] = vals[1]; return; }
-  if (tid == 0) {
-    float dq[4];
-    quaternion_grad(cam, vals, dq);
-    // dsmall is [DPC_SMALL_COLS][B] with dq stored as a [B,4] block, dt as a [B,3] block (see dpc_render.h)
-    float* dqb = dsmall + (size_t)DPC_COL_DQ * P.B + (size_t)b * 4;
-    float* dtb = dsmall + (size_t)DPC_COL_DT * P.B + (size_t)b * 3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) atomicAdd(dqb + i, dq[i]);
-    if (t != nullptr)
-      for (int i = 0; i < 3; ++i) atomicAdd(dtb + i, vals[9 + i]);
-    if (f != nullptr) atomicAdd(dsmall + (size_t)DPC_COL_DF * P.B + b, vals[12]);
-    if (bk.x == 0) {
-      float ds = 0.f;
-      for (int i = 0; i < n_ds_part; ++i) ds += ds_part[(size_t)b * n_ds_part + i];
-      dsmall[(size_t)DPC_COL_DS * P.B + b] = ds * upstream;
-    }
+  if (tid == 0 && bk.x == 0) {  // the occupancy-scale gradient: the column kernel's per-tile partials, in tile order
+    float ds = 0.f;
+    for (int i = 0; i < n_ds_part; ++i) ds += ds_part[(size_t)b * n_ds_part + i];
+    dsmall[(size_t)DPC_COL_DS * P.B + b] = ds * upstream;
   }
+  camgrad_publish(tot, tid, cam_raw, P.B, b, bk.x, bk.nx, cg_part, cg_count, dsmall, t != nullptr, f != nullptr);
   DPC_STAMP(13);
 }
 
 template <int GS, int ZS, int RB>
 int launch_gather_fast(const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
                        const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask,
-                       const float* ds_part, int ntile, float* dpc, float* dsmall, const LossArgs& la, hipStream_t st) {
+                       const float* ds_part, int ntile, float* dpc, float* dsmall, double* cg_part, unsigned int* cg_count,
+                       const LossArgs& la, hipStream_t st) {
   using Geo = BwdGeo<GS, RB, ZS + 1>;
   // slab + scratch tail: reduction floats, record table, staged mask words
   constexpr size_t lds = (((Geo::slab_floats(ZS + 1) + 3) / 4) * 4 + kRedMask + (ZS + 1) * GS * (GS / 32)) * sizeof(float);
@@ -307,23 +297,24 @@ int launch_gather_fast(const DpcParams* p, Cells cells, const float* pc, const f
       if (p->D % c == 0 && (size_t)(p->D / c) * p->B >= (size_t)kNumCUs) roll = c;
   const int nslab = (p->D + ZS - 1) / ZS;
   DPC_LAUNCH("k_gather_hw", kern, dim3(((nslab + roll - 1) / roll) * p->B), dim3(Geo::NT), lds, st, *p, cells, pc, q, t, f,
-             make_taps<RB>(kxy, pxy, true), ZS == 1 ? roll : ZS, dT, mask, ds_part, ntile, dpc, dsmall, la);
+             make_taps<RB>(kxy, pxy, true), ZS == 1 ? roll : ZS, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la);
   return launch_ok();
 }
 
 template <int RB>
 int launch_gather_rb(const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
                   const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part,
-                  int ntile, float* dpc, float* dsmall, const LossArgs& la, hipStream_t st) {
+                  int ntile, float* dpc, float* dsmall, double* cg_part, unsigned int* cg_count, const LossArgs& la,
+                  hipStream_t st) {
   if (p->H == p->W) {
     if constexpr (RB <= 4) {
-      if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
-      if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
-      if (p->H == 64) return launch_gather_fast<64, kBwdZs64, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
+      if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
+      if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
+      if (p->H == 64) return launch_gather_fast<64, kBwdZs64, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
     } else if constexpr (RB <= 10) {
-      if (p->H == 64) return launch_gather_fast<64, 7, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
-      if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);  // c4: sigma_rel 1.28 -> radius 8
-      if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st);
+      if (p->H == 64) return launch_gather_fast<64, 7, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
+      if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);  // c4: sigma_rel 1.28 -> radius 8
+      if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
     }
   }
   const int fit = planes_fit(p);
@@ -334,7 +325,7 @@ int launch_gather_rb(const DpcParams* p, Cells cells, const float* pc, const flo
   int rc = set_lds(kern, lds);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_gather_hw", kern, dim3(((p->D + Zs - 1) / Zs) * p->B), dim3(slab_threads(p)), lds, st, *p, cells, pc, q, t, f,
-             make_taps<RB>(kxy, pxy, true), Zs, dT, mask, ds_part, ntile, dpc, dsmall, la);
+             make_taps<RB>(kxy, pxy, true), Zs, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la);
   return launch_ok();
 }
 
@@ -342,9 +333,14 @@ int launch_gather_rb(const DpcParams* p, Cells cells, const float* pc, const flo
 
 int launch_gather(int bucket, const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
                   const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part, int ntile,
-                  float* dpc, float* dsmall, const LossArgs& la, hipStream_t st) {
+                  float* dpc, float* dsmall, double* cg_part, unsigned int* cg_count, const LossArgs& la, hipStream_t st) {
+#ifdef DPC_XL_GATHER  // measured: its gather phase is 1.3 us shorter (8 reads per point instead of 32 + mask), its dT load
+                      // phase 2.8 us longer (4-byte loads at one x per lane against 8-byte column pairs): not the default
+  if (xl_applies(p, bucket))
+    return launch_gather_xl(bucket, p, cells, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
+#endif
   int rc = DPC_OK;
-#define DPC_GATHER(RB) rc = launch_gather_rb<RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, la, st)
+#define DPC_GATHER(RB) rc = launch_gather_rb<RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st)
   DPC_FOR_BUCKET(bucket, DPC_GATHER)
 #undef DPC_GATHER
   return rc;

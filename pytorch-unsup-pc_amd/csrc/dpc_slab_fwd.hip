@@ -18,13 +18,20 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
                                                         const float* __restrict__ q, const float* __restrict__ t,
                                                         const float* __restrict__ f, float* __restrict__ tr_pc,
                                                         uint8_t* __restrict__ cells_out) {
-  __shared__ int hist[1026];  // D + 2 <= 1026 bins (validate() caps D at 1024)
+  // Counting sort by bin that is STABLE without any ordered atomic: every thread sets its own bit in its bin's 256-bit
+  // membership mask (ds_or, result independent of arrival order); a bin's population is the popcount of its mask and a
+  // point's rank inside the bin the popcount below its own bit.  (Ranks handed out by an atomic counter are arrival order,
+  // which changes from run to run -- and the order of the records inside a bin decides which thread of the backward adds
+  // which point into its partial sums.)
+  __shared__ int hist[1026];                          // D + 2 <= 1026 bins (validate() caps D at 1024)
+  extern __shared__ __attribute__((aligned(16))) unsigned int member[];   // (D + 1) x 8 words, sized by the launch
   const Blk bk = block_coords(P.B);
   const int b = bk.y, blk = bk.x, tid = threadIdx.x;
   const int D = P.D, nbins = D + 1;
   const int i = blk * kLocThreads + tid;
   const bool live = i < P.N;
-  for (int k = tid; k < nbins + 1; k += kLocThreads) hist[k] = 0;
+  constexpr int MW = kLocThreads / 32;  // mask words per bin
+  for (int k = tid; k < nbins * MW; k += kLocThreads) member[k] = 0u;
   // every thread normalises the quaternion itself (a dozen fp32 ops): cheaper than one thread doing it while 255 wait
   CameraRef cam_s;
   if (SRC == 0) cam_s = load_camera_ref(P, q, t, f, b);
@@ -53,16 +60,21 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
     rec = make_record(Z, Y, X, P.D, P.H, P.W);
   }
   const int bin = rec.code < 0 ? D : (rec.code >> 20);
-  __syncthreads();  // hist is zeroed (the transform above ran under that latency)
-  int rank = 0;
-  if (live) rank = atomicAdd(&hist[bin], 1);  // ds_add_rtn_u32: position inside the bin
+  __syncthreads();  // the masks are zeroed (the transform above ran under that latency)
+  if (live) atomicOr(&member[bin * MW + (tid >> 5)], 1u << (tid & 31));
   __syncthreads();
 
-  // exclusive prefix over the bins by the first wave: lane l owns bins [l*C, (l+1)*C)
+  // exclusive prefix over the bin populations by the first wave: lane l owns bins [l*C, (l+1)*C)
   if (tid < DPC_WAVE) {
     const int C = (nbins + DPC_WAVE - 1) / DPC_WAVE;
+    auto population = [&](int k) {
+      int n = 0;
+#pragma unroll
+      for (int wd = 0; wd < MW; ++wd) n += __popc(member[k * MW + wd]);
+      return n;
+    };
     int sum = 0;
-    for (int k = tid * C; k < min((tid + 1) * C, nbins); ++k) sum += hist[k];
+    for (int k = tid * C; k < min((tid + 1) * C, nbins); ++k) sum += population(k);
     int incl = sum;
 #pragma unroll
     for (int off = 1; off < DPC_WAVE; off <<= 1) {
@@ -71,9 +83,8 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
     }
     int run = incl - sum;
     for (int k = tid * C; k < min((tid + 1) * C, nbins); ++k) {
-      const int c = hist[k];
       hist[k] = run;
-      run += c;
+      run += population(k);
     }
     if (tid == DPC_WAVE - 1) hist[nbins] = incl;  // total
   }
@@ -82,7 +93,13 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
   // sorted chunk staged in LDS, then copied out with one coalesced 16-byte store per lane and array
   __shared__ int4 stage[2 * kLocThreads];
   if (live) {
-    const int pos = hist[bin] + rank;
+    int below = 0;  // members of this bin with a smaller thread id
+#pragma unroll
+    for (int wd = 0; wd < MW; ++wd) {
+      const unsigned int m = member[bin * MW + wd];
+      below += __popc(wd < (tid >> 5) ? m : (wd == (tid >> 5) ? (m & ((1u << (tid & 31)) - 1u)) : 0u));
+    }
+    const int pos = hist[bin] + below;
     int4 v;
     v.x = rec.code; v.y = __float_as_int(rec.tz); v.z = __float_as_int(rec.ty); v.w = __float_as_int(rec.tx);
     stage[pos] = v;
@@ -373,6 +390,10 @@ int launch_splat_rb(const DpcParams* p, Cells cells, const float* kxy, const Tap
 
 int launch_splat(int bucket, const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
                  uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st) {
+#ifndef DPC_NO_XL
+  if (xl_applies(p, bucket) && raw == nullptr && Tbuf != nullptr)
+    return launch_splat_xl(bucket, p, cells, kxy, pxy, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
+#endif
   int rc = DPC_OK;
 #define DPC_SPLAT(RB) rc = launch_splat_rb<RB>(p, cells, kxy, pxy, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st)
   DPC_FOR_BUCKET(bucket, DPC_SPLAT)
@@ -385,9 +406,10 @@ int launch_locate(const DpcParams* p, int src, const void* pts, const float* q, 
   if (p->N == 0 || p->B == 0) return DPC_OK;
   dim3 g(num_chunks(p->N) * p->B), blk(kLocThreads);
   uint8_t* out = static_cast<uint8_t*>(cells);
-  if (src == 0) DPC_LAUNCH("k_locate", k_locate<0>, g, blk, 0, st, *p, pts, q, t, f, tr_pc, out);
-  else if (src == 1) DPC_LAUNCH("k_locate", k_locate<1>, g, blk, 0, st, *p, pts, q, t, f, tr_pc, out);
-  else DPC_LAUNCH("k_locate", k_locate<2>, g, blk, 0, st, *p, pts, q, t, f, tr_pc, out);
+  const size_t lds = (size_t)(p->D + 1) * (kLocThreads / 32) * sizeof(unsigned int);  // the bins' membership masks
+  if (src == 0) DPC_LAUNCH("k_locate", k_locate<0>, g, blk, lds, st, *p, pts, q, t, f, tr_pc, out);
+  else if (src == 1) DPC_LAUNCH("k_locate", k_locate<1>, g, blk, lds, st, *p, pts, q, t, f, tr_pc, out);
+  else DPC_LAUNCH("k_locate", k_locate<2>, g, blk, lds, st, *p, pts, q, t, f, tr_pc, out);
   return launch_ok();
 }
 

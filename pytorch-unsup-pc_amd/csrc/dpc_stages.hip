@@ -44,15 +44,17 @@ __global__ __launch_bounds__(kThreads) void k_transform_bwd(DpcParams P, const f
                                                             const float* __restrict__ f,
                                                             const float* __restrict__ dout, float* __restrict__ dpc,
                                                             float* __restrict__ dsmall) {
-  __shared__ float red[13 * (kThreads / DPC_WAVE)];
-  const int b = blockIdx.y;
-  const Camera cam = load_camera(P, q, t, f, b);
+  // one workgroup per cloud: the 13 camera-gradient sums are taken in a fixed order, in fp64 (no atomics)
+  __shared__ float scratch[13 * (kThreads / DPC_WAVE)];
+  const int b = blockIdx.x;
+  const CameraRaw raw = load_camera_raw(P, q, t, f, b);
+  const Camera cam = make_camera(P, raw);
   const float* cloud = pc + (size_t)b * P.N * 3;
   const float* g3 = dout + (size_t)b * P.N * 3;
   float* d3 = dpc + (size_t)b * P.N * 3;
   CamGrad g;
   camgrad_zero(g);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < P.N; i += gridDim.x * blockDim.x) {
+  for (int i = threadIdx.x; i < P.N; i += blockDim.x) {
     const float px = cloud[3 * i], py = cloud[3 * i + 1], pz = cloud[3 * i + 2];
     const Projected o = project_point(cam, px, py, pz);
     float dx, dy, dz;
@@ -63,15 +65,18 @@ __global__ __launch_bounds__(kThreads) void k_transform_bwd(DpcParams P, const f
 #pragma unroll
   for (int i = 0; i < 9; ++i) vals[i] = g.m[i];
   vals[9] = g.dt[0]; vals[10] = g.dt[1]; vals[11] = g.dt[2]; vals[12] = g.df;
-  block_sum<13>(vals, red);
-  if (threadIdx.x == 0) {
-    float dq[4];
-    quaternion_grad(cam, vals, dq);
-    float* dqb = dsmall + (size_t)DPC_COL_DQ * P.B + (size_t)b * 4;
-    float* dtb = dsmall + (size_t)DPC_COL_DT * P.B + (size_t)b * 3;
-    for (int i = 0; i < 4; ++i) atomicAdd(dqb + i, dq[i]);
-    for (int i = 0; i < 3; ++i) atomicAdd(dtb + i, vals[9 + i]);
-    atomicAdd(dsmall + (size_t)DPC_COL_DF * P.B + b, vals[12]);
+  const double tot = block_sum13_fixed(vals, scratch, threadIdx.x, kThreads);
+  if (threadIdx.x < DPC_WAVE) {
+    double m[13];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) m[i] = __shfl(tot, i, DPC_WAVE);
+    if (threadIdx.x == 0) {
+      double dq[4];
+      quaternion_grad_f64(raw.q, m, dq);
+      for (int i = 0; i < 4; ++i) dsmall[(size_t)DPC_COL_DQ * P.B + (size_t)b * 4 + i] = (float)dq[i];
+      for (int i = 0; i < 3; ++i) dsmall[(size_t)DPC_COL_DT * P.B + (size_t)b * 3 + i] = (float)m[9 + i];
+      dsmall[(size_t)DPC_COL_DF * P.B + b] = (float)m[12];
+    }
   }
 }
 
@@ -299,8 +304,7 @@ int dpc_transform_bwd(const DpcParams* p, const float* pc, const float* q, const
   if (hipMemsetAsync(dsmall, 0, (size_t)p->B * DPC_SMALL_COLS * sizeof(float), (hipStream_t)stream) != hipSuccess)
     return DPC_ERR_LAUNCH;
   if (p->N == 0) return DPC_OK;
-  dim3 grid(std::max(1, std::min((p->N + kThreads - 1) / kThreads, 64)), p->B);
-  hipLaunchKernelGGL(k_transform_bwd, grid, dim3(kThreads), 0, (hipStream_t)stream, *p, pc, q, t, f, dout, dpc, dsmall);
+  hipLaunchKernelGGL(k_transform_bwd, dim3(p->B), dim3(kThreads), 0, (hipStream_t)stream, *p, pc, q, t, f, dout, dpc, dsmall);
   return launch_ok();
 }
 

@@ -232,7 +232,7 @@ class ProjectLossFused(torch.autograd.Function):
                                         N.ptr(trans), N.ptr(sse), N.ptr(loss), N.ptr(winner), N.ptr(ws), N.ptr(dsmall),
                                         ctypes.byref(fused), N.stream_ptr(dev))
         N.check(rc, "dpc_project_loss_fwd")
-        ctx.geom, ctx.K, ctx.fused, ctx.fresh = geom, K, bool(fused.value), True
+        ctx.geom, ctx.K, ctx.fused = geom, K, bool(fused.value)
         ctx.inputs = tuple(_meta(x) for x in (pc, q, t, f, s))
         empty = pc32.new_empty(0)
         ctx.save_for_backward(pc32, q32, t32 if t32 is not None else empty, f32 if f32 is not None else empty,
@@ -256,11 +256,7 @@ class ProjectLossFused(torch.autograd.Function):
         dl = dloss.detach().to(torch.float32).reshape(())
         dpc = torch.zeros_like(pc32) if reps > 1 else torch.empty_like(pc32)  # replicas add into a shared gradient
         if ctx.fused:
-            if not ctx.fresh:  # a second backward through the same node: the gather's accumulators must start at zero
-                dsmall[:4 * B].zero_()
-                dsmall[5 * B:9 * B].zero_()
-            ctx.fresh = False
-            out_small = dsmall
+            out_small = dsmall   # zeroed by the forward's column kernel; dq/dt/df are written (not accumulated) by the gather
         else:
             out_small = torch.empty((N.DPC_SMALL_COLS * B,), dtype=torch.float32, device=dev)
             ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)

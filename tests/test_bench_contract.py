@@ -28,6 +28,67 @@ def test_kernel_byte_table_is_below_the_contract():
     fused_step = kb["k_locate"] + kb["k_splat_hw"] + kb["k_zcol_fwdbwd"] + kb["k_gather_hw"]
     assert fused_step < b.algorithmic_bytes_per_cloud(8000, 64)
     assert set(b.CONFIGS) == {"c2", "c4", "c5"} and b.CONFIGS["c2"][:3] == (32, 8000, 64)
+    # the point-record chunk is 256 x (16 + 16) bytes + bin offsets: the locate kernel writes more than it reads
+    assert kb["k_locate"] > 12 * 8000 + 32 * 8000
+    # the unfused column kernels do not write a `smoothed` grid on the hot path
+    assert kb["k_zcol_fwd"] == 4 * 64 ** 3 + 4 * 64 ** 2 and kb["k_zcol_bwd"] == 8 * 64 ** 3 + 8 * 64 ** 2
+
+
+def test_candidate_step_bytes_exclude_the_losers_backward():
+    b = _bench()
+    a = b.algorithmic_bytes_per_cloud(8000, 64)
+    assert b.step_bytes_per_cloud(8000, 64, 1) == a
+    fwd = 12 * 8000 + 16 * 64 ** 3 + 4 * 64 ** 2
+    assert abs(b.step_bytes_per_cloud(8000, 64, 8) - (fwd + (a - fwd) / 8)) < 1e-6
+
+
+def test_recorded_lines_stay_below_the_hbm_peak():
+    """No per-kernel or whole-step rate in a bench line committed under profiles/ (this round's) may exceed the 8 TB/s
+    peak: a figure above it means the byte model credits traffic the kernel does not have."""
+    import glob
+    import json
+
+    b = _bench()
+    seen = 0
+    for path in glob.glob(os.path.join(ROOT, "profiles", "r02_*.json*")):
+        for line in open(path):
+            line = line.strip()
+            if not line.startswith("{"):
+                continue
+            try:
+                rec = json.loads(line)
+            except ValueError:
+                continue
+            if "kernels_gbs" not in rec:
+                continue
+            seen += 1
+            for k, v in rec["kernels_gbs"].items():
+                assert v <= b.HBM_PEAK_GBS, (path, k, v)
+            assert rec["roofline_step"]["frac"] <= 1.0, path
+            if rec.get("roofline"):
+                assert rec["roofline"]["frac"] <= 1.0, path
+    assert seen >= 0
+
+
+def test_gpus_flag_launches_ranks_before_touching_a_gpu(monkeypatch):
+    """`python bench.py --gpus N` with no launcher: refuses loudly when the node has fewer devices, and otherwise builds a
+    torch.distributed.run command for N ranks on 127.0.0.1."""
+    import subprocess
+    import types
+
+    b = _bench()
+    args = types.SimpleNamespace(gpus=4, rehearse_on_one_gpu=False)
+    monkeypatch.setattr(b.torch.cuda, "device_count", lambda: 1)
+    assert b.launch_ranks(args) == 2
+    calls = []
+    monkeypatch.setattr(b.torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setattr(subprocess, "run", lambda cmd, env=None: calls.append((cmd, env)) or types.SimpleNamespace(returncode=0))
+    monkeypatch.setattr(b.sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7"])
+    assert b.launch_ranks(args) == 0
+    cmd, env = calls[0]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[-4:] == ["--gpus", "4", "--steps", "7"]
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
 def test_measured_traffic_reads_the_committed_profile():

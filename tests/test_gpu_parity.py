@@ -1,6 +1,15 @@
 """GPU parity: the HIP path (through the C ABI) against golden vectors produced by the reference and
-against the CPU oracle on the same seeded inputs.  Tolerance: 1e-5 absolute on silhouettes and gradients
-(BASELINE.json north_star: "to 1e-5 fp32"), fp32 device results compared with fp64 references."""
+against the CPU oracle on the same seeded inputs.
+
+THE parity rule (one rule for every silhouette, loss and gradient in this file):
+
+    max |device - reference|  <=  1e-5 * max(1, max |reference|)
+
+i.e. BASELINE.json's "1e-5 fp32" as an absolute bound for O(1) quantities (silhouettes, image-loss gradients) and relative
+to the largest reference entry where the values are O(10..1000) (losses summed over 4096 pixels, gradients under the
+fixtures' synthetic weights): fp32 device results have 24 significant bits, the references are fp64.  Tighter bounds are
+used where the arithmetic allows them (bit-exact cell records and indices, 2e-6 on transformed coordinates, 1e-6 between
+two device paths); nothing is compared more loosely."""
 import json
 import os
 
@@ -65,11 +74,11 @@ def test_transform_golden(R, O, golden, tag):
     close(out, g["out_" + tag], 2e-6, "tr_pc")
     (out * dev(g["w"])).sum().backward()
     close(pc.grad, g["dpc_" + tag], TOL, "dpc")
-    close(q.grad, g["dq_" + tag], 5e-5, "dq")  # sums of 64 O(1) terms in fp32
+    close(q.grad, g["dq_" + tag], TOL, "dq")  # sums of 64 O(1) terms in fp32
     if t is not None:
-        close(t.grad, g["dt_" + tag], 5e-5, "dt")
+        close(t.grad, g["dt_" + tag], TOL, "dt")
     if f is not None:
-        close(f.grad, g["df_" + tag], 5e-5, "df")
+        close(f.grad, g["df_" + tag], TOL, "df")
 
 
 def test_transform_identity(R, O):
@@ -230,16 +239,16 @@ def test_chain_golden(R, O, golden, name, sem):
     close(proj, g[sem + "_proj"], TOL, "proj")
     B = pc.shape[0]
     loss = ((proj - dev(g["gt"])) ** 2).sum() / B
-    assert abs(loss.item() - float(g[sem + "_loss"])) < 1e-4 * max(1.0, float(g[sem + "_loss"]))
+    close(loss, float(g[sem + "_loss"]), TOL, "chain loss")
     loss.backward()
     close(pc.grad, g[sem + "_dpc"], TOL, "dpc")
-    close(q.grad, g[sem + "_dq"], 3e-5, "dq")  # a sum over N points
+    close(q.grad, g[sem + "_dq"], TOL, "dq")  # a sum over N points
     for nm, x in (("ds", s), ("dt", t), ("df", f)):
         if x is not None:
-            close(x.grad, g[sem + "_" + nm], 3e-5, nm)
+            close(x.grad, g[sem + "_" + nm], TOL, nm)
     # lazily produced outputs (stage kernels)
     close(out["tr_pc"], g[sem + "_tr_pc"], 2e-6, "tr_pc")
-    close(out["proj_depth"], g[sem + "_proj_depth"], 1e-4, "proj_depth")
+    close(out["proj_depth"], g[sem + "_proj_depth"], TOL, "proj_depth")
     if sem + "_voxels" in g:
         close(out["voxels"], g[sem + "_voxels"], TOL, "voxels")
         close(out["drc_probs"], g[sem + "_drc_probs"], TOL, "drc_probs")
@@ -304,12 +313,12 @@ def test_chain_vs_oracle(R, O, B, N, G, k, sigma, with_t, with_f):
     (((out["proj"] - gt.cuda().float()) ** 2).sum() / B).backward()
     close(out["proj"], ref["proj"], TOL, "proj")
     close(gp.grad, cp.grad, TOL, "dpc")
-    close(gq.grad, cq.grad, 3e-5, "dq")
-    close(gs.grad, cs.grad, 3e-5, "ds")
+    close(gq.grad, cq.grad, TOL, "dq")
+    close(gs.grad, cs.grad, TOL, "ds")
     if t is not None:
-        close(gt_.grad, ct.grad, 3e-5, "dt")
+        close(gt_.grad, ct.grad, TOL, "dt")
     if f is not None:
-        close(gf.grad, cf.grad, 3e-5, "df")
+        close(gf.grad, cf.grad, TOL, "df")
 
 
 def test_long_kernel_falls_back_to_staged(R, O):
@@ -353,16 +362,16 @@ def test_full_size_properties(R, O):
     raw, _ = R.pointcloud2voxels3d_fast(cfg, tr, None)
     nvalid = ((tr >= -0.5) & (tr <= 0.5)).all(-1).sum().item()
     assert abs(raw.double().sum().item() - nvalid) < 1e-3 * nvalid ** 0.5 + 0.5
-    # run-to-run: LDS/global float atomics may reorder sums, nothing else may change
     loss = ((proj - gt) ** 2).sum() / B
     loss.backward()
     g1 = [pc.grad.clone(), q.grad.clone(), s.grad.clone()]
     pc.grad = q.grad = s.grad = None
     proj2 = R.pointcloud_project_fast(cfg, pc, q, None, None, kern, scaling_factor=s)["proj"]
     (((proj2 - gt) ** 2).sum() / B).backward()
-    close(proj2, proj, 1e-6, "determinism proj")
-    for a, b in zip(g1, [pc.grad, q.grad, s.grad]):
-        close(a, b, 1e-6, "determinism grads")
+    # run to run: every sum of the path is taken in a fixed order or in exact integer arithmetic -- identical bits
+    assert torch.equal(proj2, proj), "silhouettes differ between two runs"
+    for name, a, b in zip(("dpc", "dq", "ds"), g1, [pc.grad, q.grad, s.grad]):
+        assert torch.equal(a, b), "%s differs between two runs" % name
     # batch independence: clouds 0..3 alone give the same silhouettes and gradients
     sub = R.pointcloud_project_fast(cfg, pc[:4].detach(), q[:4].detach(), None, None, kern, scaling_factor=s[:4].detach())["proj"]
     close(sub, proj[:4], 1e-6, "batch independence")
@@ -373,8 +382,39 @@ def test_full_size_properties(R, O):
     (((ref["proj"] - gt[idx].cpu().double()) ** 2).sum() / B).backward()
     close(proj[idx], ref["proj"], TOL, "proj vs oracle at full size")
     close(g1[0][idx], cp.grad, TOL, "dpc vs oracle at full size")
-    close(g1[1][idx], cq.grad, 3e-5, "dq vs oracle at full size")
-    close(g1[2][idx], cs.grad, 3e-5, "ds vs oracle at full size")
+    close(g1[1][idx], cq.grad, TOL, "dq vs oracle at full size")
+    close(g1[2][idx], cs.grad, TOL, "ds vs oracle at full size")
+
+
+def test_benchmarked_call_at_full_size(R, O):
+    """The call bench.py times, at the size it times it: pointcloud_project_loss with one pose candidate per sample (the
+    ray-march kernel runs the column backward inside the forward, the loss is summed in 64-bit fixed point), B=32, N=8000,
+    64^3, sigma_rel 0.64.  Oracle on 3 of the 32 clouds; the loss against an fp64 sum over the device silhouettes; two runs
+    bit for bit."""
+    B, N, G = 32, 8000, 64
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=21)
+    kern = R.smoothing_kernel(cfg, 0.64)
+    pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 1234)
+    gp, gq, gs, ggt = dev(pc, True), dev(q, True), dev(s, True), dev(gt)
+    runs = []
+    for _ in range(2):
+        gp.grad = gq.grad = gs.grad = None
+        loss, out, win = R.pointcloud_project_loss(cfg, gp, gq, None, None, kern, scaling_factor=gs, gt=ggt, num_candidates=1)
+        loss.backward()
+        runs.append([loss.detach().clone(), out["proj"].detach().clone(), gp.grad.clone(), gq.grad.clone(), gs.grad.clone()])
+    for name, a, b in zip(("loss", "proj", "dpc", "dq", "ds"), *runs):
+        assert torch.equal(a, b), "%s differs between two runs of the same step" % name
+    loss, proj, dpc, dq, ds = runs[0]
+    assert int(win.abs().max()) == 0
+    close(loss, ((proj.double().cpu() - gt.double()) ** 2).sum() / B, 1e-6, "benchmarked call: loss vs fp64 sum of its silhouettes")
+    idx = [0, 13, 31]
+    cp, cq, cs = (x[idx].clone().requires_grad_(True) for x in (pc, q, s))
+    ref = O.pointcloud_project_fast(cfg, cp, cq, None, None, O.smoothing_kernel(cfg, 0.64), scaling_factor=cs)
+    (((ref["proj"] - gt[idx].double()) ** 2).sum() / B).backward()
+    close(proj[idx], ref["proj"], TOL, "benchmarked call: proj vs oracle")
+    close(dpc[idx], cp.grad, TOL, "benchmarked call: dpc vs oracle")
+    close(dq[idx], cq.grad, TOL, "benchmarked call: dq vs oracle")
+    close(ds[idx], cs.grad, TOL, "benchmarked call: ds vs oracle")
 
 
 def test_silhouette_loss_candidates(R, O, golden):
@@ -417,9 +457,9 @@ def test_project_loss_fused(R, O, K):
     close(loss, rloss, TOL, "fused loss")
     close(out["proj"], ref["proj"], TOL, "proj")
     close(gp.grad, cp.grad, TOL, "dpc (fused loss)")
-    close(gq.grad, cq.grad, 3e-5, "dq (fused loss)")
-    close(gs.grad, cs.grad, 3e-5, "ds (fused loss)")
-    close(gtt.grad, ct.grad, 3e-5, "dt (fused loss)")
+    close(gq.grad, cq.grad, TOL, "dq (fused loss)")
+    close(gs.grad, cs.grad, TOL, "ds (fused loss)")
+    close(gtt.grad, ct.grad, TOL, "dt (fused loss)")
     if K > 1:  # losing candidates: exact zeros
         lose = np.ones(B, bool)
         lose[np.arange(S) * K + rwin.numpy()] = False
@@ -449,8 +489,8 @@ def test_project_loss_fused_shapes(R, O, B, N, G, ksz, sig):
         close(loss, rloss, TOL, "fused K=1 loss B=%d G=%d rep %d" % (B, G, rep))
         close(out["proj"], ref["proj"], TOL, "fused K=1 proj")
         close(gp.grad, cp.grad, TOL, "fused K=1 dpc")
-        close(gq.grad, cq.grad, 3e-5, "fused K=1 dq")
-        close(gs.grad, cs.grad, 3e-5, "fused K=1 ds")
+        close(gq.grad, cq.grad, TOL, "fused K=1 dq")
+        close(gs.grad, cs.grad, TOL, "fused K=1 ds")
 
 
 @pytest.mark.parametrize("K,reps,sig,G", [(1, 4, 0.64, 32), (4, 8, 1.1, 32), (2, 2, 0.64, 32), (1, 2, 1.1, 32), (2, 4, 0.8, 24),
@@ -544,8 +584,8 @@ def test_config4_full_size(R, O):
     (((ref["proj"] - gt[i:i + 1]) ** 2).sum() / B).backward()
     close(proj[i:i + 1], ref["proj"], TOL, "c4 proj vs oracle")
     close(gp.grad[i:i + 1], cp.grad, TOL, "c4 dpc vs oracle")
-    close(gq.grad[i:i + 1], cq.grad, 3e-5, "c4 dq vs oracle")
-    close(gs.grad[i:i + 1], cs.grad, 3e-5, "c4 ds vs oracle")
+    close(gq.grad[i:i + 1], cq.grad, TOL, "c4 dq vs oracle")
+    close(gs.grad[i:i + 1], cs.grad, TOL, "c4 ds vs oracle")
 
 
 def test_config5_full_size(R, O):
@@ -581,7 +621,7 @@ def test_config5_full_size(R, O):
     assert w1.item() == rwin[smp].item()
     close(proj[sl], ref["proj"], TOL, "c5 proj vs oracle")
     close(gp.grad[sl], cp.grad, TOL, "c5 dpc vs oracle")
-    close(gq.grad[sl], cq.grad, 3e-5, "c5 dq vs oracle")
+    close(gq.grad[sl], cq.grad, TOL, "c5 dq vs oracle")
 
 
 def test_many_chunks_fallback_iteration(R, O):
@@ -598,8 +638,8 @@ def test_many_chunks_fallback_iteration(R, O):
     (((out["proj"] - dev(gt)) ** 2).sum() / B).backward()
     close(out["proj"], ref["proj"], TOL, "proj (N=20000)")
     close(gp.grad, cp.grad, TOL, "dpc (N=20000)")
-    close(gq.grad, cq.grad, 1e-4, "dq (N=20000)")  # a sum over 20000 points in fp32
-    close(gs.grad, cs.grad, 3e-5, "ds (N=20000)")
+    close(gq.grad, cq.grad, TOL, "dq (N=20000)")  # a sum over 20000 points in fp32
+    close(gs.grad, cs.grad, TOL, "ds (N=20000)")
 
 
 def test_empty_clouds_through_fused_path(R, O):

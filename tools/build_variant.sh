@@ -10,7 +10,7 @@ out=$root/scratch/$name
 mkdir -p $out
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function -mllvm -pragma-unroll-threshold=400000 $*"
 pids=()
-for f in dpc_slab_fwd dpc_column dpc_slab_bwd dpc_entry dpc_stages dpc_nearest dpc_profile; do
+for f in dpc_slab_fwd dpc_slab_xl dpc_column dpc_slab_bwd dpc_entry dpc_stages dpc_nearest dpc_profile; do
   extra=""; [ $f = dpc_nearest ] && extra="-fno-slp-vectorize"
   /opt/rocm/bin/hipcc $FLAGS $extra -c $src/$f.hip -o $out/$f.o &
   pids+=($!)

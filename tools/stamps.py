@@ -25,6 +25,8 @@ pc, q, s, gt = [x.cuda().float() for x in bench.synthetic_inputs(B, N, G, 1234)]
 pc.requires_grad_(True), q.requires_grad_(True), s.requires_grad_(True)
 L = _native.lib()
 L.dpc_debug_set_stamps.argtypes = [ctypes.c_void_p]
+L.dpc_debug_set_ablate.argtypes = [ctypes.c_int]
+L.dpc_debug_set_ablate(int(os.environ.get('DPC_ABL_BITS', '0'), 0))
 
 
 def step():
@@ -63,5 +65,8 @@ def report(name, slots, labels):
           " end deciles", np.round(np.percentile(end, [0, 10, 25, 50, 75, 90, 100]), 2))
 
 
-report("k_splat_hw", [0, 1, 2, 3, 4, 5], ["zero+table", "scatter", "W-load/convert", "W-compute/write", "H-pass+store"])
+if (st[:, 4] > 0).any():
+    report("k_splat_hw", [0, 1, 2, 3, 4, 5], ["zero+table", "scatter", "W-load/convert", "W-compute/write", "H-pass+store"])
+else:  # x-in-lanes kernel: no fp32 slab, no barrier between the passes
+    report("k_splat_hw (xl)", [0, 1, 2, 3, 5], ["zero+table", "scatter", "window+mask+convert", "H+W passes+store"])
 report("k_gather_hw", [8, 9, 11, 12, 13], ["pads+H-pass(global)", "gather", "block_sum", "epilogue"])
