@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DPC_ABI_VERSION 9
+#define DPC_ABI_VERSION 10
 #define DPC_MAX_TAPS 63 /* longest 1-D smoothing kernel accepted (pc_gauss_kernel_size) */
 
 enum {
@@ -62,6 +62,14 @@ typedef struct DpcParams {
                             * THE CALLER: the replicas' gradients are added into it.  0 or 1: every cloud has its own
                             * points.  Honoured by the fused entry points (dpc_project_*); the stage entry points require
                             * R <= 1. */
+  int32_t N_src;           /* points per stored point set when point_index is given (>= 1), otherwise ignored     */
+  const int32_t* point_index; /* DEVICE pointer [B,N] int32 | NULL: cloud b projects the points
+                            * pc[b/R][point_index[b*N + i]], i < N, of a stored set of N_src points -- every replica
+                            * of a point set keeps its own random subset (pc_point_dropout applied after tf_repeat_0,
+                            * dpc/models/model_pc_to.py:254-258, 302-306; dpc/util/point_cloud_to.py:269-295) without the
+                            * [B,N,3] copies.  Then `pc` is [B/R,N_src,3] and `dpc` is [B/R,N_src,3], ZERO-INITIALISED BY
+                            * THE CALLER (the selected points' gradients are added into it; indices may repeat).
+                            * Honoured by dpc_locate and the fused entry points; the stage entry points require NULL. */
 } DpcParams;
 
 /* Small per-cloud gradients written by the backward entry points: one buffer of DPC_SMALL_COLS * B floats made of

@@ -84,6 +84,8 @@ __device__ inline Blk block_coords(int clouds) {
   return k;
 }
 
+__host__ __device__ inline int points_per_set(const DpcParams& P) { return P.point_index != nullptr ? P.N_src : P.N; }
+
 __device__ inline int odd_stride(int w) { return w | 1; }  // generic LDS row stride: odd => conflict-free column walks
 
 // ------------------------------------------------------------------------------------------------------
@@ -566,6 +568,7 @@ inline int validate(const DpcParams* p) {
   if (p->B < 0 || p->N < 0 || p->D < 1 || p->H < 1 || p->W < 1) return DPC_ERR_SHAPE;
   if (p->D > 1024 || p->H > 1024 || p->W > 1024 || p->B > 65535) return DPC_ERR_SHAPE;  // 10-bit cell indices
   if (p->point_replicas < 0 || (p->point_replicas > 1 && p->B % p->point_replicas != 0)) return DPC_ERR_SHAPE;
+  if (p->point_index != nullptr && p->N_src < 1) return DPC_ERR_SHAPE;
   for (int taps : {p->taps_xy, p->taps_z})
     if (taps < 0 || taps > DPC_MAX_TAPS || (taps > 0 && taps % 2 == 0)) return DPC_ERR_TAPS;
   return DPC_OK;

@@ -22,7 +22,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
                                                             double* __restrict__ cg_part,
                                                             unsigned int* __restrict__ cg_count, LossArgs la) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
-  const int D = P.D, H = P.H, W = P.W, N = P.N, HW = H * W;
+  const int D = P.D, H = P.H, W = P.W, HW = H * W;
   const int Zs = GS ? ZS : zs_rt;
   // One-layer slabs (planes too big for more: 128^2) ROLL: the workgroup walks `roll` consecutive layers, keeps the plane
   // two layers share in LDS (ping-pong of the two plane buffers) and pays start-up, reduction and atomics once.
@@ -31,13 +31,16 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   const Blk bk = block_coords(P.B);
   const int b = bk.y, z0 = bk.x * Zs * roll;
   const int reps = P.point_replicas > 1 ? P.point_replicas : 1;
-  const bool shared_points = reps > 1;  // dpc is [B/reps,N,3], zeroed by the caller; replicas add into it
+  // replicas of a point set, or clouds that picked their points out of a stored set: dpc is [B/reps,Nset,3], zeroed by the
+  // caller, and every cloud ADDS its gradients into it
+  const bool shared_points = reps > 1 || P.point_index != nullptr;
+  const int Nset = points_per_set(P);
   if (cloud_loses(la, b)) {  // a losing pose candidate: zero gradient, no work (block-uniform)
     if (shared_points) {
       if (bk.x == 0 && threadIdx.x == 0) dsmall[(size_t)DPC_COL_DS * P.B + b] = 0.f;
       return;
     }
-    float* dz = dpc + (size_t)b * N * 3;
+    float* dz = dpc + (size_t)b * Nset * 3;
     auto zero3 = [&](const PointRec&, const int4* aux) {
       const int i = aux->w;
       dz[3 * i + 0] = 0.f; dz[3 * i + 1] = 0.f; dz[3 * i + 2] = 0.f;
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   const Camera cam = make_camera(P, cam_raw);
   CamGrad g;
   camgrad_zero(g);
-  float* dcloud = dpc + (size_t)(b / reps) * N * 3;
+  float* dcloud = dpc + (size_t)(b / reps) * Nset * 3;
   auto corner = [&](int zz, int yy, int xx) -> float {
     if constexpr (GS > 0) return slab[BwdGeo<GS, RB, ZS + 1>::at(zz, yy, xx)];
     else return slab[(zz * H + yy) * odd_stride(W) + xx];

@@ -39,12 +39,14 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
   PointRec rec;
   rec.code = -1; rec.tz = rec.ty = rec.tx = 0.f;
   float src_pt[3] = {0.f, 0.f, 0.f};  // the untransformed point (SRC 0), carried next to its record for the backward
+  int src_i = i;                      // ... and its index inside the stored point set (where its gradient goes)
   if (live) {
     const size_t idx = (size_t)b * P.N + i;
     double Z, Y, X;
     if (SRC == 0) {
       const int reps = P.point_replicas > 1 ? P.point_replicas : 1;  // replicas of one point set read the same rows
-      const float* p = static_cast<const float*>(pts) + ((size_t)(b / reps) * P.N + i) * 3;
+      if (P.point_index != nullptr) src_i = P.point_index[idx];       // this cloud's own subset of the stored set
+      const float* p = static_cast<const float*>(pts) + ((size_t)(b / reps) * points_per_set(P) + src_i) * 3;
       src_pt[0] = p[0]; src_pt[1] = p[1]; src_pt[2] = p[2];
       project_point_ref(cam_s, p[0], p[1], p[2], Z, Y, X);
       if (tr_pc != nullptr) {
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
     v.x = rec.code; v.y = __float_as_int(rec.tz); v.z = __float_as_int(rec.ty); v.w = __float_as_int(rec.tx);
     stage[pos] = v;
     int4 a;
-    a.x = __float_as_int(src_pt[0]); a.y = __float_as_int(src_pt[1]); a.z = __float_as_int(src_pt[2]); a.w = i;
+    a.x = __float_as_int(src_pt[0]); a.y = __float_as_int(src_pt[1]); a.z = __float_as_int(src_pt[2]); a.w = src_i;
     stage[kLocThreads + pos] = a;
   }
   __syncthreads();

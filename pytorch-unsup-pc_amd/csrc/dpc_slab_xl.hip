@@ -221,18 +221,21 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_xl(DpcParams P, Cells c
   extern __shared__ __attribute__((aligned(16))) float slab[];
   constexpr int NPL = ZS + 1, NT = kSlabThreads, NW = NT / DPC_WAVE, WIN = kXSeg + 2 * RB;
   constexpr int NITEM = NPL * kXSegs, IPT = (NITEM + NW - 1) / NW;   // 36 items, 3 per wave on 12 of the 16 waves
-  const int D = P.D, N = P.N;
+  const int D = P.D;
   const Blk bk = block_coords(P.B);
   const int b = bk.y, z0 = bk.x * ZS;
   const int reps = P.point_replicas > 1 ? P.point_replicas : 1;
-  const bool shared_points = reps > 1;  // dpc is [B/reps,N,3], zeroed by the caller; replicas add into it
+  // replicas of a point set, or clouds that picked their points out of a stored set: dpc is [B/reps,Nset,3], zeroed by the
+  // caller, and every cloud ADDS its gradients into it
+  const bool shared_points = reps > 1 || P.point_index != nullptr;
+  const int Nset = points_per_set(P);
   const int tid = threadIdx.x;
   if (cloud_loses(la, b)) {  // a losing pose candidate: zero gradient, no work (block-uniform)
     if (shared_points) {
       if (bk.x == 0 && tid == 0) dsmall[(size_t)DPC_COL_DS * P.B + b] = 0.f;
       return;
     }
-    float* dz = dpc + (size_t)b * N * 3;
+    float* dz = dpc + (size_t)b * Nset * 3;
     auto zero3 = [&](const PointRec&, const int4* aux) {
       const int i = aux->w;
       dz[3 * i + 0] = 0.f; dz[3 * i + 1] = 0.f; dz[3 * i + 2] = 0.f;
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_xl(DpcParams P, Cells c
   const Camera cam = make_camera(P, cam_raw);
   CamGrad g;
   camgrad_zero(g);
-  float* dcloud = dpc + (size_t)(b / reps) * N * 3;
+  float* dcloud = dpc + (size_t)(b / reps) * Nset * 3;
   auto gather = [&](const PointRec& rec, const int4* aux) {
     const int4 pt = *aux;  // {px, py, pz, original index}
     const int i = pt.w;

@@ -14,7 +14,7 @@ int validate(const DpcParams* p) {
   if (p == nullptr) return DPC_ERR_NULL;
   if (p->B < 0 || p->N < 0 || p->D < 1 || p->H < 1 || p->W < 1) return DPC_ERR_SHAPE;
   if (p->D > 1024 || p->H > 1024 || p->W > 1024 || p->B > 65535) return DPC_ERR_SHAPE;  // 10-bit cell indices
-  if (p->point_replicas < 0 || p->point_replicas > 1) return DPC_ERR_SHAPE;  // shared point sets: fused entry points only
+  if (p->point_replicas < 0 || p->point_replicas > 1 || p->point_index != nullptr) return DPC_ERR_SHAPE;  // shared / indexed point sets: fused entry points only
   for (int taps : {p->taps_xy, p->taps_z})
     if (taps < 0 || taps > DPC_MAX_TAPS || (taps > 0 && taps % 2 == 0)) return DPC_ERR_TAPS;
   return DPC_OK;

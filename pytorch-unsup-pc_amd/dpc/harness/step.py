@@ -10,6 +10,7 @@ student, learned occupancy scale, no rgb / depth / drc losses, no translation, f
     renderer + min-of-K silhouette loss in ONE call (dpc.render.pointcloud_project_loss)
     student loss against the winning candidate, (proj + student) * proj_weight, backward, Adam
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -38,12 +39,12 @@ def student_loss(poses, student, winner, num_candidates, weight):
 
 def device_point_dropout(points, keep_prob, generator=None):
     """pc_point_dropout (point_cloud_to.py:269-295) without the host: int(N*keep) distinct random points per cloud,
-    chosen by ranking device-side uniforms.  Same distribution as the reference's np.random.choice(replace=False),
-    different random stream (no numpy RNG, index upload or sync inside the step)."""
+    chosen by ranking device-side uniforms (dpc.render.point_dropout_indices).  Same distribution as the reference's
+    np.random.choice(replace=False), different random stream.  Materialises the kept points; the
+    training step below hands the INDICES to the renderer instead and keeps the point sets shared."""
     B, N = points.shape[0], points.shape[1]
-    keep = int(N * keep_prob)
-    idx = torch.rand(B, N, device=points.device, generator=generator).topk(keep, dim=1).indices
-    return points.gather(1, idx.unsqueeze(-1).expand(B, keep, 3))
+    idx = R.point_dropout_indices(B, N, keep_prob, points.device, generator)
+    return points.gather(1, idx.long().unsqueeze(-1).expand(B, idx.shape[1], 3))
 
 
 class TrainStep:
@@ -72,16 +73,21 @@ class TrainStep:
         out = self.predict(images)
         K, V = cfg.pose_predict_num_candidates, cfg.step_size
         all_scales = out["scaling_factor"].repeat_interleave(V * K, dim=0) if cfg.pc_learn_occupancy_scaling else None
-        if cfg.pc_point_dropout != 1:
-            all_points = out["points_1"].repeat_interleave(V * K, dim=0)      # tf_repeat_0 twice (:302-306)
-            keep = R.get_dropout_prob(cfg, step)                              # every replica drops its own points
-            all_points = device_point_dropout(all_points, keep) if self.device_dropout else R.pc_point_dropout(all_points, None, keep)[0]
-        else:
-            all_points = out["points_1"]  # [B,N,3] shared by the V*K clouds of an object: the renderer reads it in place
+        all_points, point_index = out["points_1"], None  # [B,N,3] shared by the V*K clouds of an object, read in place
+        if cfg.pc_point_dropout != 1:                     # every replica drops its own points (:254-258 after :302-306)
+            keep = R.get_dropout_prob(cfg, step)
+            clouds = all_points.shape[0] * V * K
+            if self.device_dropout:
+                point_index = R.point_dropout_indices(clouds, all_points.shape[1], keep, all_points.device)
+            else:  # the reference's host RNG protocol (one np.random.choice per cloud, in batch order), indices only
+                n_out = int(all_points.shape[1] * keep)
+                host = np.stack([np.random.choice(all_points.shape[1], n_out, replace=False) for _ in range(clouds)])
+                point_index = torch.from_numpy(host.astype(np.int32)).to(all_points.device)
         kernel = R.smoothing_kernel(cfg, R.get_smooth_sigma(cfg, step))
         gt = pooled_masks(masks, cfg.vox_size)
         proj_loss, proj_out, winner = R.pointcloud_project_loss(cfg, all_points, out["poses"], None, None, kernel,
-                                                                scaling_factor=all_scales, gt=gt, num_candidates=K)
+                                                                scaling_factor=all_scales, gt=gt, num_candidates=K,
+                                                                point_index=point_index)
         total = proj_loss.double()
         if K > 1 and cfg.pose_predictor_student:
             out["student_loss"] = student_loss(out["poses"], out["pose_student"], winner, K, cfg.pose_predictor_student_loss_weight)

@@ -25,7 +25,7 @@ __all__ = [
     "drc_projection", "drc_event_probabilities", "drc_depth_projection", "drc_depth_grid", "pc_point_dropout",
     "quaternion_rotate", "quaternion_multiply", "quaternion_conjugate", "quaternion_normalise",
     "get_smooth_sigma", "get_dropout_prob", "ProjectionOutputs", "silhouette_loss", "pointcloud_project_loss",
-    "point_cloud_distance", "compute_distance", "chamfer_distances", "graphed_project_loss",
+    "point_cloud_distance", "compute_distance", "chamfer_distances", "graphed_project_loss", "point_dropout_indices",
 ]
 
 
@@ -254,10 +254,12 @@ class ProjectionOutputs(dict):
         return dict.items(self)
 
 
-def _project_staged(cfg, geom, pc, q, t, f, s, smooth):
+def _project_staged(cfg, geom, pc, q, t, f, s, smooth, point_index=None):
     """The same chain composed from the stage-level kernels (all differentiable)."""
     if pc.shape[0] != q.shape[0]:  # shared point sets: the stage kernels want one cloud per pose
         pc = pc.repeat_interleave(q.shape[0] // pc.shape[0], dim=0)
+    if point_index is not None:    # every cloud's own subset, materialised
+        pc = pc.gather(1, point_index.long().unsqueeze(-1).expand(-1, -1, 3))
     tr = Transform.apply(pc, q, t, f, geom)
     raw = Splat.apply(tr, geom)
     vox = torch.clamp(raw, 0.0, 1.0)
@@ -273,7 +275,7 @@ def _project_staged(cfg, geom, pc, q, t, f, s, smooth):
 
 
 def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation, all_rgb, kernel=None,
-                            scaling_factor=None, focal_length=None, smooth=True):
+                            scaling_factor=None, focal_length=None, smooth=True, point_index=None):
     """Project [B,N,3] point clouds to [B,H,W,1] silhouettes (dpc/util/point_cloud_to.py:191-263).
 
     Same positional signature as the reference; returns a dict with the reference's keys
@@ -283,15 +285,21 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation, 
     Shared point sets: `point_cloud` may be [B/R,N,3] while `transform` (and the other per-cloud
     inputs) have B rows -- clouds b*R .. b*R+R-1 then use point set b, the layout tf_repeat_0 produces for the views and
     pose candidates of one object (dpc/models/model_pc_to.py:302-306), without materialising the B copies; the
-    gradient comes back as [B/R,N,3], summed over the replicas inside the backward kernel."""
+    gradient comes back as [B/R,N,3], summed over the replicas inside the backward kernel.
+
+    Per-cloud point subsets (point dropout without copies): `point_index` [B,n] integer tensor -- cloud b projects the points
+    point_cloud[b // R][point_index[b]] only.  This is pc_point_dropout applied AFTER tf_repeat_0 as the reference does
+    (model_pc_to.py:254-258: every replica drops its own points) with neither the replicated [B,N,3] tensor nor the
+    gathered [B,n,3] one; the gradient has the shape of `point_cloud` (zeros at points no cloud kept).  Indices from
+    dpc.render.point_dropout_indices (device RNG) or any other source; they may repeat."""
     if all_rgb is not None:
         raise NotImplementedError("all_rgb: the rgb branch of the reference is dead (point_cloud_to.py:64 AttributeError)")
     _check_live_branches(cfg)
     geom = _geometry(cfg, kernel if smooth else None)
     staged = lambda: _project_staged(cfg, geom, point_cloud, transform, predicted_translation, focal_length,
-                                     scaling_factor, smooth)
+                                     scaling_factor, smooth, point_index)
     try:
-        proj = ProjectFused.apply(point_cloud, transform, predicted_translation, focal_length, scaling_factor, geom)
+        proj = ProjectFused.apply(point_cloud, transform, predicted_translation, focal_length, scaling_factor, geom, point_index)
     except _native.DpcError as e:
         if e.code != _native.DPC_ERR_TAPS:
             raise
@@ -306,7 +314,7 @@ pointcloud_project = pointcloud_project_fast
 
 
 def pointcloud_project_loss(cfg, point_cloud, transform, predicted_translation, all_rgb, kernel=None,
-                            scaling_factor=None, focal_length=None, gt=None, num_candidates=1, smooth=True):
+                            scaling_factor=None, focal_length=None, gt=None, num_candidates=1, smooth=True, point_index=None):
     """pointcloud_project_fast followed by the model's projection loss, as ONE autograd node.
 
     What ModelPointCloud does in two steps -- compute_projection (dpc/models/model_pc_to.py:239-282) then
@@ -315,7 +323,8 @@ def pointcloud_project_loss(cfg, point_cloud, transform, predicted_translation, 
     S*num_candidates clouds (candidate-minor, like tf_repeat_0).  Returns (loss, outputs, winner): the scalar
     loss sum_s min_k sum (gt-pred)^2 / S, the usual output dict (`proj` from this pass, the rest lazy), and the
     winning candidate per sample.  Falls back to pointcloud_project_fast + silhouette_loss when the Gaussian is
-    too long for the fused kernels.  `point_cloud` may hold shared point sets ([B/R,N,3], see pointcloud_project_fast)."""
+    too long for the fused kernels.  `point_cloud` may hold shared point sets ([B/R,N,3]) and `point_index` per-cloud
+    subsets of them (see pointcloud_project_fast)."""
     if all_rgb is not None:
         raise NotImplementedError("all_rgb: the rgb branch of the reference is dead (point_cloud_to.py:64 AttributeError)")
     if gt is None:
@@ -323,15 +332,16 @@ def pointcloud_project_loss(cfg, point_cloud, transform, predicted_translation, 
     _check_live_branches(cfg)
     geom = _geometry(cfg, kernel if smooth else None)
     staged = lambda: _project_staged(cfg, geom, point_cloud, transform, predicted_translation, focal_length,
-                                     scaling_factor, smooth)
+                                     scaling_factor, smooth, point_index)
     try:
         loss, proj, winner = ProjectLossFused.apply(point_cloud, transform, predicted_translation, focal_length,
-                                                    scaling_factor, gt, geom, num_candidates)
+                                                    scaling_factor, gt, geom, num_candidates, point_index,
+                                                    torch.is_grad_enabled())
     except _native.DpcError as e:
         if e.code != _native.DPC_ERR_TAPS:
             raise
         out = pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation, None, kernel, scaling_factor,
-                                      focal_length, smooth)
+                                      focal_length, smooth, point_index)
         loss, winner = silhouette_loss(out["proj"], gt, num_candidates)
         return loss, out, winner
     return loss, ProjectionOutputs(proj, staged), winner
@@ -366,6 +376,17 @@ def pc_point_dropout(points, rgb, keep_prob):
     out_points = points[rows, idx_t]
     out_rgb = rgb[rows, idx_t] if rgb is not None else None
     return out_points, out_rgb
+
+
+def point_dropout_indices(num_clouds, num_points, keep_prob, device, generator=None):
+    """Indices of pc_point_dropout (point_cloud_to.py:269-295) drawn on the device: for each of `num_clouds` clouds,
+    int(num_points * keep_prob) DISTINCT point indices, uniformly random (the ranks of num_points uniform numbers: the same
+    distribution as the reference's np.random.choice(replace=False), a different random stream).  int32 [num_clouds, n]
+    for the `point_index` argument of pointcloud_project_fast / pointcloud_project_loss; no host work, no upload, no sync,
+    safe inside HIP-graph capture."""
+    keep = int(num_points * keep_prob)
+    u = torch.rand(num_clouds, num_points, device=device, generator=generator)
+    return u.topk(keep, dim=1).indices.to(torch.int32)
 
 
 # ------------------------------------------------------------------------------------------------------

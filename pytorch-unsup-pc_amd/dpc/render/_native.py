@@ -14,7 +14,7 @@ _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__))
 # other implementation to fall back to either way
 LIB_PATH = os.environ.get("DPC_RENDER_LIB") or os.path.join(_CSRC, "libdpc_render.so")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 DPC_MAX_TAPS = 63
 DPC_SMALL_COLS = 12
 COL_DQ, COL_DS, COL_DT, COL_DF = 0, 4, 5, 8
@@ -34,7 +34,8 @@ class DpcParams(ctypes.Structure):
     _fields_ = [("B", ctypes.c_int32), ("N", ctypes.c_int32), ("D", ctypes.c_int32), ("H", ctypes.c_int32),
                 ("W", ctypes.c_int32), ("taps_xy", ctypes.c_int32), ("taps_z", ctypes.c_int32),
                 ("camera_distance", ctypes.c_float), ("focal_length", ctypes.c_float),
-                ("clip_val", ctypes.c_float), ("max_depth", ctypes.c_float), ("point_replicas", ctypes.c_int32)]
+                ("clip_val", ctypes.c_float), ("max_depth", ctypes.c_float), ("point_replicas", ctypes.c_int32),
+                ("N_src", ctypes.c_int32), ("point_index", ctypes.c_void_p)]
 
 
 class DpcError(RuntimeError):

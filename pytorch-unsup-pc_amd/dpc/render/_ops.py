@@ -30,10 +30,13 @@ class Geometry:
         self.camera_distance, self.focal_length = float(camera_distance), float(focal_length)
         self.clip_val, self.max_depth = float(clip_val), float(max_depth)
 
-    def params(self, B, Npts, point_replicas=1):
+    def params(self, B, Npts, point_replicas=1, point_index=None, n_src=0):
+        """point_index: int32 device tensor [B,Npts] (kept alive by the caller for the duration of the call) selecting
+        every cloud's points out of a stored set of n_src points."""
         return N.DpcParams(int(B), int(Npts), self.D, self.H, self.W,
                            0 if self.kxy is None else self.kxy.size, 0 if self.kz is None else self.kz.size,
-                           self.camera_distance, self.focal_length, self.clip_val, self.max_depth, int(point_replicas))
+                           self.camera_distance, self.focal_length, self.clip_val, self.max_depth, int(point_replicas),
+                           int(n_src), None if point_index is None else point_index.data_ptr())
 
     def kern_ptrs(self):
         if self.kxy is None:
@@ -53,6 +56,18 @@ def _replicas(pc, q):
     if S == 0 or B % S:
         raise ValueError("%d poses cannot share %d point sets: the number of clouds must be a multiple" % (B, S))
     return B // S
+
+
+def _index32(point_index, pc, q):
+    """Per-cloud point selection [B,n] -> contiguous int32 on the inputs' device (None passes through)."""
+    if point_index is None:
+        return None
+    if point_index.dim() != 2 or point_index.shape[0] != q.shape[0]:
+        raise ValueError("point_index must be [%d, n] (one row of point indices per cloud), got %s"
+                         % (q.shape[0], tuple(point_index.shape)))
+    if point_index.device != pc.device:
+        raise RuntimeError("point_index lives on %s, the points on %s" % (point_index.device, pc.device))
+    return point_index.detach().to(torch.int32).contiguous()
 
 
 def _meta(t):
@@ -129,12 +144,14 @@ class ProjectFused(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, pc, q, t, f, s, geom):
+    def forward(ctx, pc, q, t, f, s, geom, point_index=None):
         dev = N.require_device(pc, q, t, f, s)
         L = N.lib()
         pc32, q32, t32, f32, s32 = _f32(pc), _f32(q), _f32(t), _f32(f), _f32(s)
-        B, Npts, reps = q32.shape[0], pc32.shape[1], _replicas(pc32, q32)
-        P = geom.params(B, Npts, reps)
+        idx = _index32(point_index, pc32, q32)
+        B, reps = q32.shape[0], _replicas(pc32, q32)
+        Npts = pc32.shape[1] if idx is None else idx.shape[1]
+        P = geom.params(B, Npts, reps, idx, pc32.shape[1])
         wpp = L.dpc_mask_words_per_plane(ctypes.byref(P))
         grid_wh = torch.empty((B, geom.D, geom.H, geom.W), dtype=torch.float32, device=dev)
         mask = torch.empty((B, geom.D, wpp), dtype=torch.int64, device=dev)
@@ -153,13 +170,14 @@ class ProjectFused(torch.autograd.Function):
         ctx.save_for_backward(pc32, q32, t32 if t32 is not None else empty, f32 if f32 is not None else empty,
                               s32 if s32 is not None else empty, grid_wh, mask, cells, trans)
         ctx.has = (t is not None, f is not None, s is not None)
+        ctx.npts, ctx.indexed = Npts, idx is not None
         ctx.set_materialize_grads(False)
         return proj
 
     @staticmethod
     def backward(ctx, dproj):
         if dproj is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         pc32, q32, t32, f32, s32, grid_wh, mask, cells, trans = ctx.saved_tensors
         has_t, has_f, has_s = ctx.has
         t32 = t32 if has_t else None
@@ -168,10 +186,11 @@ class ProjectFused(torch.autograd.Function):
         geom = ctx.geom
         dev = pc32.device
         L = N.lib()
-        B, Npts, reps = q32.shape[0], pc32.shape[1], _replicas(pc32, q32)
-        P = geom.params(B, Npts, reps)
+        B, reps = q32.shape[0], _replicas(pc32, q32)
+        P = geom.params(B, ctx.npts, reps, cells if ctx.indexed else None, pc32.shape[1])  # the backward reads the source
+        # index out of the binned records; any non-NULL pointer says "dpc is per stored set, accumulate"
         dproj32 = dproj.detach().to(torch.float32).contiguous()
-        dpc = torch.zeros_like(pc32) if reps > 1 else torch.empty_like(pc32)  # replicas add into a shared gradient
+        dpc = torch.zeros_like(pc32) if (reps > 1 or ctx.indexed) else torch.empty_like(pc32)  # clouds add into a shared gradient
         dsmall = torch.empty((N.DPC_SMALL_COLS * B,), dtype=torch.float32, device=dev)
         ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
         kxy, kz = geom.kern_ptrs()
@@ -184,7 +203,7 @@ class ProjectFused(torch.autograd.Function):
         return (_like_input(dpc, pc), _like_input(_small(dsmall, N.COL_DQ, 4, B), q),
                 _like_input(_small(dsmall, N.COL_DT, 3, B), t) if has_t else None,
                 _like_input(_small(dsmall, N.COL_DF, 1, B), f) if has_f else None,
-                _like_input(_small(dsmall, N.COL_DS, 1, B), s) if has_s else None, None)
+                _like_input(_small(dsmall, N.COL_DS, 1, B), s) if has_s else None, None, None)
 
 
 class ProjectLossFused(torch.autograd.Function):
@@ -198,11 +217,13 @@ class ProjectLossFused(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, pc, q, t, f, s, gt, geom, num_candidates):
+    def forward(ctx, pc, q, t, f, s, gt, geom, num_candidates, point_index=None, want_grad=True):
         dev = N.require_device(pc, q, t, f, s, gt)
         L = N.lib()
         pc32, q32, t32, f32, s32, gt32 = _f32(pc), _f32(q), _f32(t), _f32(f), _f32(s), _f32(gt)
-        B, Npts, reps = q32.shape[0], pc32.shape[1], _replicas(pc32, q32)
+        idx = _index32(point_index, pc32, q32)
+        B, reps = q32.shape[0], _replicas(pc32, q32)
+        Npts = pc32.shape[1] if idx is None else idx.shape[1]
         K = int(num_candidates)
         if K < 1 or B % K:
             raise ValueError("%d clouds is not a multiple of %d pose candidates" % (B, K))
@@ -210,7 +231,7 @@ class ProjectLossFused(torch.autograd.Function):
         if gt32.shape[0] != S or gt32[0].numel() != geom.H * geom.W:
             raise ValueError("gt must be [%d,%d,%d,1] (masks pooled to the silhouette size), got %s"
                              % (S, geom.H, geom.W, tuple(gt32.shape)))
-        P = geom.params(B, Npts, reps)
+        P = geom.params(B, Npts, reps, idx, pc32.shape[1])
         wpp = L.dpc_mask_words_per_plane(ctypes.byref(P))
         f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         grid_wh, proj, trans = f32e(B, geom.D, geom.H, geom.W), f32e(B, geom.H, geom.W, 1), f32e(B, geom.H, geom.W)
@@ -218,8 +239,9 @@ class ProjectLossFused(torch.autograd.Function):
         mask = torch.empty((B, geom.D, wpp), dtype=torch.int64, device=dev)
         winner = torch.empty((S,), dtype=torch.int32, device=dev)
         cells = _new_cells(P, dev)
-        # backward buffers handed to the forward so it can run the column half of the backward right away
-        want_grad = any(x is not None and x.requires_grad for x in (pc, q, t, f, s))
+        # backward buffers handed to the forward so it can run the column half of the backward right away -- only when a
+        # backward can follow (grad mode is always off INSIDE forward(): the caller passes what it saw outside)
+        want_grad = want_grad and any(x is not None and x.requires_grad for x in (pc, q, t, f, s))
         ws = dsmall = None
         if want_grad and K == 1:
             ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
@@ -239,6 +261,7 @@ class ProjectLossFused(torch.autograd.Function):
                               s32 if s32 is not None else empty, gt32, grid_wh, mask, cells, proj, trans, winner,
                               ws if ctx.fused else empty, dsmall if ctx.fused else empty)
         ctx.has = (t is not None, f is not None, s is not None)
+        ctx.npts, ctx.indexed = Npts, idx is not None
         ctx.set_materialize_grads(False)
         ctx.mark_non_differentiable(proj, winner)
         return loss, proj, winner
@@ -246,15 +269,15 @@ class ProjectLossFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss, _dproj, _dwinner):
         if dloss is None:
-            return (None,) * 8
+            return (None,) * 10
         pc32, q32, t32, f32, s32, gt32, grid_wh, mask, cells, proj, trans, winner, ws, dsmall = ctx.saved_tensors
         has_t, has_f, has_s = ctx.has
         t32, f32, s32 = (t32 if has_t else None), (f32 if has_f else None), (s32 if has_s else None)
         geom, dev, L = ctx.geom, pc32.device, N.lib()
-        B, Npts, reps = q32.shape[0], pc32.shape[1], _replicas(pc32, q32)
-        P = geom.params(B, Npts, reps)
+        B, reps = q32.shape[0], _replicas(pc32, q32)
+        P = geom.params(B, ctx.npts, reps, cells if ctx.indexed else None, pc32.shape[1])  # see ProjectFused.backward
         dl = dloss.detach().to(torch.float32).reshape(())
-        dpc = torch.zeros_like(pc32) if reps > 1 else torch.empty_like(pc32)  # replicas add into a shared gradient
+        dpc = torch.zeros_like(pc32) if (reps > 1 or ctx.indexed) else torch.empty_like(pc32)  # clouds add into a shared gradient
         if ctx.fused:
             out_small = dsmall   # zeroed by the forward's column kernel; dq/dt/df are written (not accumulated) by the gather
         else:
@@ -271,7 +294,7 @@ class ProjectLossFused(torch.autograd.Function):
         return (_like_input(dpc, pc), _like_input(_small(out_small, N.COL_DQ, 4, B), q),
                 _like_input(_small(out_small, N.COL_DT, 3, B), t) if has_t else None,
                 _like_input(_small(out_small, N.COL_DF, 1, B), f) if has_f else None,
-                _like_input(_small(out_small, N.COL_DS, 1, B), s) if has_s else None, None, None, None)
+                _like_input(_small(out_small, N.COL_DS, 1, B), s) if has_s else None, None, None, None, None, None)
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -535,6 +535,117 @@ def test_shared_point_sets(R, O, K, reps, sig, G):
         R.pointcloud_project_fast(cfg, dev(pc[:2]), dev(q[:3]), None, None, kern)
 
 
+@pytest.mark.parametrize("K,reps,G,sig", [(1, 4, 32, 1.1), (2, 4, 32, 0.64), (4, 8, 64, 0.64), (1, 1, 32, 1.1)])
+def test_point_index_vs_oracle(R, O, K, reps, G, sig):
+    """Per-replica point dropout inside the kernels (reference: tf_repeat_0 then pc_point_dropout,
+    dpc/models/model_pc_to.py:254-258, 302-306): cloud b projects point_cloud[b // R][point_index[b]].  Against the ORACLE
+    on the materialised clouds -- silhouettes, winners, loss, d(pc) summed over the replicas into the stored sets (zeros
+    where no replica kept the point), d(q), d(s) -- for the plain projection and for the fused min-of-K loss."""
+    S, Nsrc, keep = 3, 1100, 0.3
+    B = S * reps
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    pc, _, _, _, _, _ = O.synth_inputs(S, Nsrc, G, 4400 + K)
+    _, q, s, _, _, _ = O.synth_inputs(B, 4, G, 4500 + reps)
+    gt = O.synth_inputs(B // K, 1, G, 4600)[3]
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    idx = R.point_dropout_indices(B, Nsrc, keep, torch.device("cuda"), gen)
+    assert idx.shape == (B, int(Nsrc * keep)) and idx.dtype == torch.int32
+    rows = idx.long().cpu()
+    leaf = lambda x: x.clone().requires_grad_(True)
+    # oracle: the reference's own order of operations -- replicate, then every replica drops its points
+    cp, cq, cs = leaf(pc), leaf(q), leaf(s)
+    mat = cp.repeat_interleave(reps, dim=0).gather(1, rows.unsqueeze(-1).expand(-1, -1, 3))
+    ref = O.pointcloud_project_fast(cfg, mat, cq, None, None, O.smoothing_kernel(cfg, sig), scaling_factor=cs)
+    rloss, rwin = O.proj_loss_pose_candidates(gt, ref["proj"], K)
+    (1.5 * rloss).backward()
+    # fused loss path
+    gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+    loss, out, win = R.pointcloud_project_loss(cfg, gp, gq, None, None, R.smoothing_kernel(cfg, sig), scaling_factor=gs, gt=dev(gt),
+                                               num_candidates=K, point_index=idx)
+    (1.5 * loss).backward()
+    assert np.array_equal(win.cpu().numpy(), rwin.numpy())
+    close(loss, rloss, TOL, "point_index: fused loss")
+    close(out["proj"], ref["proj"], TOL, "point_index: proj")
+    assert gp.grad.shape == pc.shape
+    close(gp.grad, cp.grad, TOL, "point_index: dpc (fused loss)")
+    close(gq.grad, cq.grad, TOL, "point_index: dq (fused loss)")
+    close(gs.grad, cs.grad, TOL, "point_index: ds (fused loss)")
+    kept = torch.zeros(S, Nsrc, dtype=torch.bool)
+    kept[torch.arange(B).unsqueeze(1) // reps, rows] = True
+    assert float(gp.grad.cpu()[~kept].abs().max()) == 0.0, "a point no cloud kept has a gradient"
+    # plain projection path (external loss), same inputs
+    hp, hq, hs = dev(pc, True), dev(q, True), dev(s, True)
+    o2 = R.pointcloud_project_fast(cfg, hp, hq, None, None, R.smoothing_kernel(cfg, sig), scaling_factor=hs, point_index=idx)
+    w = dev(np.random.RandomState(5).rand(B, G, G, 1))
+    (o2["proj"] * w).sum().backward()
+    cp2, cq2, cs2 = leaf(pc), leaf(q), leaf(s)
+    mat2 = cp2.repeat_interleave(reps, dim=0).gather(1, rows.unsqueeze(-1).expand(-1, -1, 3))
+    ref2 = O.pointcloud_project_fast(cfg, mat2, cq2, None, None, O.smoothing_kernel(cfg, sig), scaling_factor=cs2)
+    (ref2["proj"] * w.cpu().double()).sum().backward()
+    close(o2["proj"], ref2["proj"], TOL, "point_index: proj (plain)")
+    close(hp.grad, cp2.grad, TOL, "point_index: dpc (plain)")
+    close(hq.grad, cq2.grad, TOL, "point_index: dq (plain)")
+    close(o2["tr_pc"], ref2["tr_pc"], 2e-6, "point_index: tr_pc of the kept points")
+
+
+@pytest.mark.parametrize("K,reps", [(1, 4), (4, 8)])
+def test_shared_point_sets_vs_oracle(R, O, K, reps):
+    """Shared point sets without dropout (point_cloud [B/R,N,3], B poses) against the ORACLE on the tf_repeat_0 copies
+    (dpc/models/model_pc_to.py:47-56, 302-306): silhouettes, winners, loss, d(pc) summed over the replicas, d(q), d(s)."""
+    S, N, G = 2, 1300, 32
+    B = S * reps
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    pc = O.synth_inputs(S, N, G, 5100 + K)[0]
+    _, q, s, _, _, _ = O.synth_inputs(B, 4, G, 5200)
+    gt = O.synth_inputs(B // K, 1, G, 5300)[3]
+    leaf = lambda x: x.clone().requires_grad_(True)
+    cp, cq, cs = leaf(pc), leaf(q), leaf(s)
+    ref = O.pointcloud_project_fast(cfg, cp.repeat_interleave(reps, dim=0), cq, None, None, O.smoothing_kernel(cfg, 0.9), scaling_factor=cs)
+    rloss, rwin = O.proj_loss_pose_candidates(gt, ref["proj"], K)
+    rloss.backward()
+    gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+    loss, out, win = R.pointcloud_project_loss(cfg, gp, gq, None, None, R.smoothing_kernel(cfg, 0.9), scaling_factor=gs, gt=dev(gt),
+                                               num_candidates=K)
+    loss.backward()
+    assert np.array_equal(win.cpu().numpy(), rwin.numpy())
+    close(loss, rloss, TOL, "shared sets: loss")
+    close(out["proj"], ref["proj"], TOL, "shared sets: proj")
+    close(gp.grad, cp.grad, TOL, "shared sets: dpc summed over replicas")
+    close(gq.grad, cq.grad, TOL, "shared sets: dq")
+    close(gs.grad, cs.grad, TOL, "shared sets: ds")
+
+
+def test_point_dropout_indices_properties(R):
+    """dpc.render.point_dropout_indices against the contract of pc_point_dropout (dpc/util/point_cloud_to.py:269-295): per
+    cloud int(N * keep) indices, all distinct, in range; clouds independent; a seeded generator reproduces the draw; every
+    point is kept with probability keep (uniform without replacement)."""
+    B, N, keep = 256, 1000, 0.07
+    d = torch.device("cuda")
+    g = torch.Generator(device="cuda").manual_seed(7)
+    a = R.point_dropout_indices(B, N, keep, d, g)
+    n = int(N * keep)
+    assert a.shape == (B, n) and a.dtype == torch.int32 and int(a.min()) >= 0 and int(a.max()) < N
+    srt = a.long().sort(dim=1).values
+    assert bool((srt[:, 1:] != srt[:, :-1]).all()), "a cloud kept the same point twice"
+    assert not torch.equal(srt[0], srt[1]) and len({tuple(r.tolist()) for r in srt[:32]}) == 32, "clouds share their draws"
+    again = R.point_dropout_indices(B, N, keep, d, torch.Generator(device="cuda").manual_seed(7))
+    other = R.point_dropout_indices(B, N, keep, d, torch.Generator(device="cuda").manual_seed(8))
+    assert torch.equal(a, again) and not torch.equal(a, other)
+    counts = torch.bincount(a.long().flatten(), minlength=N).double().cpu().numpy()   # ~ Binomial(B, keep) per point
+    mean, sd = B * n / N, (B * keep * (1 - keep)) ** 0.5
+    assert abs(counts.mean() - mean) < 1e-9 and counts.max() < mean + 6 * sd and counts.min() > max(0.0, mean - 6 * sd)
+    assert abs(counts.std() - sd) < 0.25 * sd
+    # keep = 1: a permutation of all points; the harness helper materialises the same selection
+    full = R.point_dropout_indices(3, 50, 1.0, d)
+    assert torch.equal(full.long().sort(dim=1).values.cpu(), torch.arange(50).repeat(3, 1))
+    from dpc.harness import device_point_dropout
+
+    pts = torch.randn(4, 100, 3, device=d)
+    sub = device_point_dropout(pts, 0.25, torch.Generator(device="cuda").manual_seed(3))
+    ind = R.point_dropout_indices(4, 100, 0.25, d, torch.Generator(device="cuda").manual_seed(3))
+    assert torch.equal(sub, pts.gather(1, ind.long().unsqueeze(-1).expand(-1, -1, 3)))
+
+
 def test_graphed_project_loss(R, O):
     """The graph-captured step for eager loops: same loss and gradients as the eager call, on the sample data and on new
     data of the same shapes, called repeatedly."""
