@@ -123,7 +123,10 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
                     float* trans, void* stream);
 
 /* Hand-written backward of the chain above (the reference relies on autograd).
- *   dproj [B,H,W] gradient w.r.t. the (flipped) silhouette
+ *   dproj    [B,H,W] gradient w.r.t. the (flipped) silhouette
+ *   dgrid_wh [B,D,H,W] | NULL: a gradient arriving at grid_wh itself, added in (callers that derive further outputs --
+ *            voxels, drc_probs, proj_depth of the reference's output dict -- from the saved grid_wh instead of running the
+ *            chain a second time)
  * outputs
  *   dpc    [B,N,3]
  *   dsmall DPC_SMALL_COLS*B floats in the block layout above (ds/dt/df only meaningful when the matching input
@@ -131,7 +134,7 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
 int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                     const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
                     const float* grid_wh, const uint64_t* mask, const float* trans /* from fwd, or NULL */,
-                    const float* dproj, float* dpc, float* dsmall, void* workspace, void* stream);
+                    const float* dproj, const float* dgrid_wh, float* dpc, float* dsmall, void* workspace, void* stream);
 
 /* The same chain with the caller's silhouette loss fused in: add_proj_loss /
  * proj_loss_pose_candidates (dpc/models/model_pc_to.py:339-385, 410-440).  Cloud b is pose candidate b % K of
@@ -180,7 +183,9 @@ int dpc_splat_fwd(const DpcParams* p, const void* tr, int tr_is_f64, void* cells
 int dpc_splat_bwd(const DpcParams* p, const void* tr, int tr_is_f64, const float* dvox, float* dtr, void* stream);
 
 /* smoothen_voxels3d (dpc/util/point_cloud_to.py:90-103): zero-padded separable correlation along W, H, D.
- * `transpose` != 0 applies the adjoint (flipped taps), i.e. the backward.  in/out [B,D,H,W]; tmp same size. */
+ * `transpose` != 0 applies the adjoint (flipped taps), i.e. the backward.  in/out [B,D,H,W]; tmp same size.
+ * p->taps_xy == 0 (or p->taps_z == 0) leaves that group of axes alone: the D pass by itself finishes a grid that already
+ * went through the W and H passes (the grid_wh of dpc_project_fwd). */
 int dpc_smooth(const DpcParams* p, const float* host_kern_xy, const float* host_kern_z, int transpose,
                const float* in, float* out, float* tmp, void* stream);
 

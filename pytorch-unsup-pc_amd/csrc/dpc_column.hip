@@ -356,7 +356,7 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
                                                           TapsT<RB> taps_adj,
                                                           float* __restrict__ dT, float* __restrict__ ds_part,
                                                           float* __restrict__ dsmall, unsigned int* __restrict__ cg_count,
-                                                          LossArgs la) {
+                                                          const float* __restrict__ dgrid_extra, LossArgs la) {
   const int HW = P.H * P.W;
   const Blk bk = block_coords(P.B);
   const int b = bk.y, ray = bk.x * kColThreads + threadIdx.x;
@@ -387,6 +387,7 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
     }
     const float g = ray_grad(P, la, dproj, proj, b, ray);
     float* out = dT + (size_t)b * DD * HW + ray;
+    const float* extra = dgrid_extra ? dgrid_extra + (size_t)b * DD * HW + ray : nullptr;  // gradient arriving at grid_wh itself
     // streaming over z: forward taps -> d(v2) -> adjoint taps, RB voxels behind
 #pragma unroll
     for (int z = 0; z < DD + RB; ++z) {
@@ -409,6 +410,7 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
           const int zz = zo + k - RB;
           if (zz >= 0 && zz < DD) acc = fmaf(taps_adj.w[k], d[zz], acc);
         }
+        if (extra != nullptr) acc += extra[(size_t)zo * HW];
         out[(size_t)zo * HW] = acc;
       }
       // keep the unrolled per-voxel chains from being interleaved across voxels (it would spill the columns)
@@ -425,7 +427,7 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHo
                                                               TapsDyn taps_adj,
                                                               float* __restrict__ dT, float* __restrict__ ds_part,
                                                               float* __restrict__ dsmall, unsigned int* __restrict__ cg_count,
-                                                              LossArgs la) {
+                                                              const float* __restrict__ dgrid_extra, LossArgs la) {
   const int HW = P.H * P.W, D = P.D;
   const Blk bk = block_coords(P.B);
   const int b = bk.y, ray = bk.x * kColThreads + threadIdx.x;
@@ -453,6 +455,7 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHo
     }
     const float g = ray_grad(P, la, dproj, proj, b, ray);
     float* out = dT + (size_t)b * D * HW + ray;
+    const float* extra = dgrid_extra ? dgrid_extra + (size_t)b * D * HW + ray : nullptr;
     for (int z = 0; z < D; ++z) {
       float term;
       const float own = drc_voxel_bwd(rc, v2_at(z), g, Tf, z == 0, term);
@@ -470,6 +473,7 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHo
           }
         }
       }
+      if (extra != nullptr) acc += extra[(size_t)z * HW];
       out[(size_t)z * HW] = acc;
     }
   }
@@ -526,7 +530,7 @@ int launch_zcol_fwd(const DpcParams* p, const float* host_kern_z, const TapPlan&
 
 int launch_zcol_bwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* grid_wh, const float* s,
                     const float* dproj, const float* proj, const float* trans, float* dT, float* ds_part, float* dsmall,
-                    unsigned int* cg_count, const LossArgs& la, hipStream_t st) {
+                    unsigned int* cg_count, const float* dgrid_extra, const LossArgs& la, hipStream_t st) {
   int rc = DPC_OK;
   const RayHost rh = ray_host(p);
   dim3 gcol(col_tiles(p) * p->B);
@@ -534,9 +538,9 @@ int launch_zcol_bwd(const DpcParams* p, const float* host_kern_z, const TapPlan&
 #define DPC_ZBWD(RB)                                                                                              \
   {                                                                                                               \
     const TapsT<RB> tz = make_taps<RB>(host_kern_z, pz, true), tzf = make_taps<RB>(host_kern_z, pz, false);       \
-    if (p->D == 32) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, cg_count, la); done = true; } \
-    else if (p->D == 64) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, cg_count, la); done = true; } \
-    else if (p->D == 128) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, cg_count, la); done = true; } \
+    if (p->D == 32) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<32, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, cg_count, dgrid_extra, la); done = true; } \
+    else if (p->D == 64) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<64, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, cg_count, dgrid_extra, la); done = true; } \
+    else if (p->D == 128) { DPC_LAUNCH("k_zcol_bwd", (k_zcol_bwd<128, RB>), gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans, tzf, tz, dT, ds_part, dsmall, cg_count, dgrid_extra, la); done = true; } \
   }
   if (pz.bucket >= 0) { DPC_FOR_BUCKET(pz.bucket, DPC_ZBWD) }
 #undef DPC_ZBWD
@@ -544,7 +548,7 @@ int launch_zcol_bwd(const DpcParams* p, const float* host_kern_z, const TapPlan&
   if (!done) {
     DPC_LAUNCH("k_zcol_bwd", k_zcol_bwd_dyn, gcol, dim3(kColThreads), 0, st, *p, rh, grid_wh, s, dproj, proj, trans,
                make_taps_dyn(host_kern_z, p->taps_z, false), make_taps_dyn(host_kern_z, p->taps_z, true), dT, ds_part,
-               dsmall, cg_count, la);
+               dsmall, cg_count, dgrid_extra, la);
   }
   return launch_ok();
 }

@@ -96,7 +96,7 @@ int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const 
 int project_bwd_impl(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, const float* s,
                      const float* host_kern_xy, const float* host_kern_z, const void* cells, const float* grid_wh,
                      const uint64_t* mask, const float* dproj, const float* proj, const float* trans, const LossArgs& la,
-                     float* dpc, float* dsmall, void* workspace, hipStream_t st) {
+                     float* dpc, float* dsmall, void* workspace, const float* dgrid_wh, hipStream_t st) {
   const bool column_done = la.scale_in_gather != 0;  // dT, ds partials and zeroed dsmall come from the forward
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
@@ -110,7 +110,7 @@ int project_bwd_impl(const DpcParams* p, const float* pc, const float* q, const 
   const Workspace w = workspace_view(p, workspace);
   const int ntile = col_tiles(p);
   if (!column_done &&
-      (rc = launch_zcol_bwd(p, host_kern_z, pz, grid_wh, s, dproj, proj, trans, w.dT, w.ds_part, dsmall, w.cg_count, la, st)) != DPC_OK)
+      (rc = launch_zcol_bwd(p, host_kern_z, pz, grid_wh, s, dproj, proj, trans, w.dT, w.ds_part, dsmall, w.cg_count, dgrid_wh, la, st)) != DPC_OK)
     return rc;
   return launch_gather(pxy.bucket, p, cells_view(p, cells), pc, q, t, f, host_kern_xy, pxy, w.dT, mask, w.ds_part, ntile, dpc,
                        dsmall, w.cg_part, w.cg_count, la, st);
@@ -131,11 +131,11 @@ int dpc_project_fwd(const DpcParams* p, const float* pc, const float* q, const f
 
 int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                     const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
-                    const float* grid_wh, const uint64_t* mask, const float* trans, const float* dproj, float* dpc,
-                    float* dsmall, void* workspace, void* stream) {
+                    const float* grid_wh, const uint64_t* mask, const float* trans, const float* dproj,
+                    const float* dgrid_wh, float* dpc, float* dsmall, void* workspace, void* stream) {
   if (!dproj) return DPC_ERR_NULL;
   return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, grid_wh, mask, dproj, nullptr, trans,
-                          kNoLoss, dpc, dsmall, workspace, (hipStream_t)stream);
+                          kNoLoss, dpc, dsmall, workspace, dgrid_wh, (hipStream_t)stream);
 }
 
 int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
@@ -172,7 +172,7 @@ int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, co
   const LossArgs la{gt, nullptr, winner, dloss, num_candidates, S > 0 ? 1.0f / (float)S : 0.f, nullptr, nullptr,
                     column_backward_done ? 1 : 0};
   return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, grid_wh, mask, nullptr, proj, trans, la,
-                          dpc, dsmall, workspace, (hipStream_t)stream);
+                          dpc, dsmall, workspace, nullptr, (hipStream_t)stream);
 }
 
 }  // extern "C"

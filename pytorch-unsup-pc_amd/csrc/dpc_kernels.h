@@ -730,7 +730,7 @@ int launch_zcol_fwdbwd(const DpcParams* p, const float* host_kern_z, const TapPl
                        unsigned int* cg_count, const LossArgs& la, hipStream_t st);
 int launch_zcol_bwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* grid_wh, const float* s,
                     const float* dproj, const float* proj, const float* trans, float* dT, float* ds_part, float* dsmall,
-                    unsigned int* cg_count, const LossArgs& la, hipStream_t st);
+                    unsigned int* cg_count, const float* dgrid_extra, const LossArgs& la, hipStream_t st);
 int launch_loss_finalize(const float* sse, int S, int K, float inv_S, float* loss, int32_t* winner, hipStream_t st);
 // dpc_slab_xl.hip: the x-in-lanes slab kernels (64 x 64 planes, radius bucket 1..6); DPC_NO_XL builds keep the older kernels
 bool xl_applies(const DpcParams* p, int bucket);

@@ -328,21 +328,30 @@ int dpc_smooth(const DpcParams* p, const float* host_kern_xy, const float* host_
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
   if (!in || !out || !tmp) return DPC_ERR_NULL;
-  if (p->taps_xy < 1 || p->taps_z < 1 || !host_kern_xy || !host_kern_z) return DPC_ERR_TAPS;
+  // taps_xy == 0 / taps_z == 0: that group of axes is left alone (e.g. the D pass alone, on a grid that already went
+  // through the W and H passes); at least one group must be given
+  const bool do_xy = p->taps_xy > 0, do_z = p->taps_z > 0;
+  if ((!do_xy && !do_z) || (do_xy && !host_kern_xy) || (do_z && !host_kern_z)) return DPC_ERR_TAPS;
   const size_t total = (size_t)p->B * p->D * p->H * p->W;
   if (total == 0) return DPC_OK;
   const bool flip = transpose != 0;
-  const TapsDyn kxy = dyn_taps(host_kern_xy, p->taps_xy, flip), kz = dyn_taps(host_kern_z, p->taps_z, flip);
+  const TapsDyn kxy = do_xy ? dyn_taps(host_kern_xy, p->taps_xy, flip) : TapsDyn{}, kz = do_z ? dyn_taps(host_kern_z, p->taps_z, flip) : TapsDyn{};
   hipStream_t st = (hipStream_t)stream;
   const dim3 g(blocks_for(total)), blk(kThreads);
   // reference order W, H, D (point_cloud_to.py:92-97); the adjoint runs D, H, W with flipped taps
-  if (!flip) {
-    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, in, out, total, p->W, 1, kxy);
-    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)out, tmp, total, p->H, p->W, kxy);
-    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)tmp, out, total, p->D, p->H * p->W, kz);
-  } else {
+  if (!do_xy) {
     hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, in, out, total, p->D, p->H * p->W, kz);
-    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)out, tmp, total, p->H, p->W, kxy);
+  } else if (!flip) {
+    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, in, do_z ? out : tmp, total, p->W, 1, kxy);
+    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)(do_z ? out : tmp), do_z ? tmp : out, total, p->H, p->W, kxy);
+    if (do_z) hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)tmp, out, total, p->D, p->H * p->W, kz);
+  } else {
+    const float* src = in;
+    if (do_z) {
+      hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, in, out, total, p->D, p->H * p->W, kz);
+      src = out;
+    }
+    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, src, tmp, total, p->H, p->W, kxy);
     hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)tmp, out, total, p->W, 1, kxy);
   }
   return launch_ok();

@@ -217,25 +217,28 @@ def drc_depth_projection(p, cfg):
 # The projection                                     reference: dpc/util/point_cloud_to.py:191-263
 # ------------------------------------------------------------------------------------------------------
 class ProjectionOutputs(dict):
-    """The reference's output dict.  `proj` (what the training loss consumes) comes from the fused kernels;
-    the other entries are produced on first access from the stage-level kernels, differentiably, so a step
-    that never reads them never pays for them."""
+    """The reference's output dict.  `proj` (what the training loss consumes) comes from the fused kernels; the other
+    entries are produced on first access, differentiably, so a step that never reads them never pays for them -- and a
+    caller that reads them every step (ModelPointCloud.compute_projection does, dpc/models/model_pc_to.py:266-269) pays for
+    what it reads only: `builder` is one callable for all lazy keys, or a dict key -> callable; a callable returns a dict
+    and may fill several keys at once."""
 
     _LAZY = ("voxels", "tr_pc", "drc_probs", "proj_depth")
 
     def __init__(self, proj, builder):
         super().__init__(proj=proj, voxels_rgb=None, proj_rgb=None)
-        self._builder = builder
+        self._builders = builder if isinstance(builder, dict) else {k: builder for k in self._LAZY}
         for k in self._LAZY:
             dict.__setitem__(self, k, None)
         self._pending = set(self._LAZY)
 
     def _materialise(self, key):
         if key in self._pending:
-            for k, v in self._builder().items():
+            for k, v in self._builders[key]().items():
                 if k in self._pending:
                     dict.__setitem__(self, k, v)
-            self._pending.clear()
+                    self._pending.discard(k)
+            self._pending.discard(key)
 
     def __getitem__(self, key):
         self._materialise(key)
@@ -245,13 +248,53 @@ class ProjectionOutputs(dict):
         self._materialise(key)
         return dict.get(self, key, default)
 
+    def _materialise_all(self):
+        for k in list(self._pending):
+            self._materialise(k)
+
     def values(self):
-        self._materialise(next(iter(self._pending), None))
+        self._materialise_all()
         return dict.values(self)
 
     def items(self):
-        self._materialise(next(iter(self._pending), None))
+        self._materialise_all()
         return dict.items(self)
+
+
+def _outputs_from_grid(cfg, geom, grid_wh, pc, q, t, f, s, point_index):
+    """Lazy entries of the output dict derived from what the fused forward left behind: `tr_pc` is one transform launch;
+    `voxels`, `drc_probs`, `proj_depth` start from grid_wh (the grid after clamp and the W, H passes, a differentiable
+    output of the fused node): D pass, occupancy scale + clamp, DRC probabilities and depth -- no second transform, splat
+    or W/H smoothing (reference: point_cloud_to.py:95-97 third pass, :218-222, :228-247)."""
+    def tr_pc():
+        pts = pc
+        if pts.shape[0] != q.shape[0]:
+            pts = pts.repeat_interleave(q.shape[0] // pts.shape[0], dim=0)
+        if point_index is not None:
+            pts = pts.gather(1, point_index.long().unsqueeze(-1).expand(-1, -1, 3))
+        return {"tr_pc": Transform.apply(pts, q, t, f, geom)}
+
+    cache = {}
+
+    def voxels():
+        if "vox" not in cache:
+            vox = grid_wh
+            if geom.kz is not None:
+                vox = Smooth.apply(vox, Geometry(geom.D, geom.H, geom.W, None, geom.kz))
+            if s is not None:
+                vox = torch.clamp(vox * s.reshape(-1, 1, 1, 1).to(vox.dtype), 0.0, 1.0)
+            cache["vox"] = vox
+        return cache["vox"]
+
+    def vox_entry():
+        return {"voxels": voxels().unsqueeze(-1)}
+
+    def drc_entries():
+        _, probs, _ = Drc.apply(voxels(), geom)
+        probs = torch.flip(probs, [2]).unsqueeze(-1)
+        return {"drc_probs": probs, "proj_depth": drc_depth_projection(probs, cfg)}
+
+    return {"tr_pc": tr_pc, "voxels": vox_entry, "drc_probs": drc_entries, "proj_depth": drc_entries}
 
 
 def _project_staged(cfg, geom, pc, q, t, f, s, smooth, point_index=None):
@@ -299,15 +342,16 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation, 
     staged = lambda: _project_staged(cfg, geom, point_cloud, transform, predicted_translation, focal_length,
                                      scaling_factor, smooth, point_index)
     try:
-        proj = ProjectFused.apply(point_cloud, transform, predicted_translation, focal_length, scaling_factor, geom, point_index)
+        proj, grid_wh = ProjectFused.apply(point_cloud, transform, predicted_translation, focal_length, scaling_factor, geom,
+                                           point_index)
     except _native.DpcError as e:
         if e.code != _native.DPC_ERR_TAPS:
             raise
         # effective Gaussian radius > 15 voxels: beyond the fused kernels' register window; same math, staged
         out = staged()
-        res = ProjectionOutputs(out["proj"], lambda: out)
-        return res
-    return ProjectionOutputs(proj, staged)
+        return ProjectionOutputs(out["proj"], lambda: out)
+    return ProjectionOutputs(proj, _outputs_from_grid(cfg, geom, grid_wh, point_cloud, transform, predicted_translation,
+                                                      focal_length, scaling_factor, point_index))
 
 
 pointcloud_project = pointcloud_project_fast

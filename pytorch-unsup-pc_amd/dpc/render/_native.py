@@ -67,7 +67,7 @@ def lib():
         L.dpc_cells_bytes.argtypes = [pp]
         L.dpc_workspace_bytes.restype = ctypes.c_size_t
         L.dpc_workspace_bytes.argtypes = [pp]
-        for name, nptr in (("dpc_project_fwd", 16), ("dpc_project_bwd", 16), ("dpc_transform_fwd", 6),
+        for name, nptr in (("dpc_project_fwd", 16), ("dpc_project_bwd", 17), ("dpc_transform_fwd", 6),
                            ("dpc_transform_bwd", 8), ("dpc_drc_fwd", 5), ("dpc_drc_bwd", 6), ("dpc_locate", 7)):
             fn = getattr(L, name)
             fn.restype = ctypes.c_int

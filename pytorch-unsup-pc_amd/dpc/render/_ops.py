@@ -22,8 +22,8 @@ class Geometry:
         self.D, self.H, self.W = int(D), int(H), int(W)
         self.kxy = None if kxy is None else np.ascontiguousarray(kxy, dtype=np.float32).reshape(-1)
         self.kz = None if kz is None else np.ascontiguousarray(kz, dtype=np.float32).reshape(-1)
-        if (self.kxy is None) != (self.kz is None):
-            raise ValueError("give both the x/y and the z kernel, or neither")
+        if self.kxy is not None and self.kz is None:
+            raise ValueError("an x/y kernel needs its z kernel (a z kernel alone is the D pass on a grid that has been through W and H)")
         for k in (self.kxy, self.kz):
             if k is not None and (k.size % 2 == 0 or k.size > N.DPC_MAX_TAPS):
                 raise ValueError("smoothing kernels must have odd length <= %d, got %d" % (N.DPC_MAX_TAPS, k.size))
@@ -39,9 +39,8 @@ class Geometry:
                            int(n_src), None if point_index is None else point_index.data_ptr())
 
     def kern_ptrs(self):
-        if self.kxy is None:
-            return None, None
-        return (self.kxy.ctypes.data_as(ctypes.c_void_p), self.kz.ctypes.data_as(ctypes.c_void_p))
+        return (None if self.kxy is None else self.kxy.ctypes.data_as(ctypes.c_void_p),
+                None if self.kz is None else self.kz.ctypes.data_as(ctypes.c_void_p))
 
 
 def _f32(t):
@@ -138,9 +137,11 @@ def locate_points(pc, q, t, f, geom):
 class ProjectFused(torch.autograd.Function):
     """pointcloud_project_fast as three launches forward, two backward (csrc/dpc_entry.hip and the kernel files it names).
 
-    forward(pc [B,N,3], q [B,4], t [B,3]|None, f [B,1]|None, s [B,1]|None, geom) -> proj [B,H,W,1]
+    forward(pc [B,N,3], q [B,4], t [B,3]|None, f [B,1]|None, s [B,1]|None, geom) -> proj [B,H,W,1], grid_wh [B,D,H,W]
     Saved for backward: the binned point records, the grid after clamp + W/H passes, the clamp mask and the per-ray
-    transmittance.
+    transmittance.  grid_wh (the grid after clamp and the W, H passes) is a differentiable output too: the other entries
+    of the reference's output dict are derived from it on demand (D pass, scale/clamp, DRC probabilities) and their
+    gradients come back through here, added to the silhouette's -- the chain never runs a second time.
     """
 
     @staticmethod
@@ -172,11 +173,11 @@ class ProjectFused(torch.autograd.Function):
         ctx.has = (t is not None, f is not None, s is not None)
         ctx.npts, ctx.indexed = Npts, idx is not None
         ctx.set_materialize_grads(False)
-        return proj
+        return proj, grid_wh
 
     @staticmethod
-    def backward(ctx, dproj):
-        if dproj is None:
+    def backward(ctx, dproj, dgrid):
+        if dproj is None and dgrid is None:
             return None, None, None, None, None, None, None
         pc32, q32, t32, f32, s32, grid_wh, mask, cells, trans = ctx.saved_tensors
         has_t, has_f, has_s = ctx.has
@@ -189,15 +190,17 @@ class ProjectFused(torch.autograd.Function):
         B, reps = q32.shape[0], _replicas(pc32, q32)
         P = geom.params(B, ctx.npts, reps, cells if ctx.indexed else None, pc32.shape[1])  # the backward reads the source
         # index out of the binned records; any non-NULL pointer says "dpc is per stored set, accumulate"
-        dproj32 = dproj.detach().to(torch.float32).contiguous()
+        dproj32 = (torch.zeros((B, geom.H, geom.W), dtype=torch.float32, device=dev) if dproj is None
+                   else dproj.detach().to(torch.float32).contiguous())
+        dgrid32 = None if dgrid is None else dgrid.detach().to(torch.float32).contiguous()
         dpc = torch.zeros_like(pc32) if (reps > 1 or ctx.indexed) else torch.empty_like(pc32)  # clouds add into a shared gradient
         dsmall = torch.empty((N.DPC_SMALL_COLS * B,), dtype=torch.float32, device=dev)
         ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
         kxy, kz = geom.kern_ptrs()
         with torch.cuda.device(dev):
             rc = L.dpc_project_bwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
-                                   N.ptr(cells), N.ptr(grid_wh), N.ptr(mask), N.ptr(trans), N.ptr(dproj32), N.ptr(dpc),
-                                   N.ptr(dsmall), N.ptr(ws), N.stream_ptr(dev))
+                                   N.ptr(cells), N.ptr(grid_wh), N.ptr(mask), N.ptr(trans), N.ptr(dproj32), N.ptr(dgrid32),
+                                   N.ptr(dpc), N.ptr(dsmall), N.ptr(ws), N.stream_ptr(dev))
         N.check(rc, "dpc_project_bwd")
         pc, q, t, f, s = ctx.inputs
         return (_like_input(dpc, pc), _like_input(_small(dsmall, N.COL_DQ, 4, B), q),
@@ -366,6 +369,7 @@ class Splat(torch.autograd.Function):
 
 
 def _smooth_call(x32, geom, transpose):
+    """geom.kxy None: the D pass alone."""
     dev = x32.device
     B = x32.shape[0]
     P = geom.params(B, 0)

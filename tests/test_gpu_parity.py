@@ -281,6 +281,38 @@ def test_fused_equals_staged(R, O, golden, name):
         close(u, v, TOL, "fused vs staged")
 
 
+@pytest.mark.parametrize("G,ksz,sig,with_s", [(32, 11, 1.2, True), (64, 21, 0.64, True), (32, 11, 1.2, False)])
+def test_dict_entries_from_the_saved_grid(R, O, G, ksz, sig, with_s):
+    """What ModelPointCloud.compute_projection does with the renderer's dict (dpc/models/model_pc_to.py:262-269): it reads
+    proj, drc_probs and proj_depth every step.  Here those entries (and voxels) come from the fused forward's grid_wh --
+    D pass, scale/clamp, DRC -- and a loss over ALL of them sends its gradients back through that grid into the one fused
+    backward.  Values and gradients against the oracle running the reference's full chain."""
+    B, N = 3, 1500
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=ksz)
+    pc, q, s, _, t, _ = O.synth_inputs(B, N, G, 6100 + G, with_t=True)
+    rs = np.random.RandomState(11)
+    w_proj, w_depth = rs.rand(B, G, G, 1), rs.rand(B, G, G, 1) * 0.1
+    w_vox, w_probs = rs.rand(B, G, G, G, 1) * 0.01, rs.rand(G + 1, B, G, G, 1) * 0.01
+    leaf = lambda x: x.clone().requires_grad_(True)
+    cp, cq, ct = leaf(pc), leaf(q), leaf(t)
+    cs = leaf(s) if with_s else None
+    ref = O.pointcloud_project_fast(cfg, cp, cq, ct, None, O.smoothing_kernel(cfg, sig), scaling_factor=cs)
+    total = lambda o, f: ((o["proj"] * f(w_proj)).sum() + (o["proj_depth"] * f(w_depth)).sum() + (o["voxels"] * f(w_vox)).sum()
+                          + (o["drc_probs"] * f(w_probs)).sum())
+    total(ref, lambda a: torch.from_numpy(a)).backward()
+    gp, gq, gt_ = dev(pc, True), dev(q, True), dev(t, True)
+    gs = dev(s, True) if with_s else None
+    out = R.pointcloud_project_fast(cfg, gp, gq, gt_, None, R.smoothing_kernel(cfg, sig), scaling_factor=gs)
+    for key in ("proj", "voxels", "drc_probs", "proj_depth"):
+        close(out[key], ref[key], TOL, "dict entry " + key)
+    total(out, dev).backward()
+    close(gp.grad, cp.grad, TOL, "dpc through the dict entries")
+    close(gq.grad, cq.grad, TOL, "dq through the dict entries")
+    close(gt_.grad, ct.grad, TOL, "dt through the dict entries")
+    if with_s:
+        close(gs.grad, cs.grad, TOL, "ds through the dict entries")
+
+
 def test_script_body_full_projection(R, O):
     """dpc/run/pc_full_proj_test.py:48-71 on the device (CUDA-branch semantics, and the literal CPU branch)."""
     vals = json.load(open(os.path.join(GOLDEN, "f7_scripts.json")))
