@@ -8,3 +8,4 @@ so that its checkpoints load unchanged.
 from .config import chair_unsupervised  # noqa: F401
 from .nets import Decoder, Encoder, PoseNet, ScalePredictor, StepNets  # noqa: F401
 from .step import TrainStep, device_point_dropout, pooled_masks, student_loss  # noqa: F401
+from .views import camera_from_blender, pool_single_view, sample_view_indices, sample_views  # noqa: F401

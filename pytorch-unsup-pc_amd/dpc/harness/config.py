@@ -25,7 +25,7 @@ def chair_unsupervised(**overrides):
         predict_translation=False, predict_translation_tanh=True, predict_translation_scaling_factor=0.15,
         pc_learn_occupancy_scaling=True, pc_occupancy_scaling_maximum=1.0, learn_focal_length=False, focal_length_mean=2.0, focal_length_range=1.0,
         # batch
-        batch_size=8, step_size=4, variable_num_views=False,
+        batch_size=8, step_size=4, variable_num_views=False, num_views_to_use=-1, saved_camera=True, saved_depth=False,
         # renderer
         vox_size=64, vox_size_z=-1, pc_gauss_kernel_size=21, pc_relative_sigma=3.0, pc_relative_sigma_end=0.2,
         camera_distance=2.0, focal_length=1.875, drc_logsum_clip_val=1e-5, max_depth=10.0,

@@ -48,10 +48,14 @@ def device_point_dropout(points, keep_prob, generator=None):
 
 
 class TrainStep:
-    def __init__(self, cfg, device, lr=1e-4, device_dropout=False):
+    def __init__(self, cfg, device, lr=1e-4, device_dropout=False, capturable=False):
+        """capturable: build Adam with its step counters on the device, so that the whole step (networks, renderer, loss,
+        backward, optimiser) can be captured into ONE HIP graph with capture()."""
         self.cfg, self.device, self.device_dropout = cfg, device, device_dropout
         self.nets = StepNets(cfg).to(device)
-        self.optimizer = torch.optim.Adam(self.nets.parameters(), lr=lr, weight_decay=cfg.weight_decay)  # train_to.py:73-74
+        self.optimizer = torch.optim.Adam(self.nets.parameters(), lr=lr, weight_decay=cfg.weight_decay,
+                                          capturable=capturable)  # train_to.py:73-74
+        self._graph = None
         self.global_step = 0
         self.grad_sync, self.sync_samples = None, (1, 1)
 
@@ -111,3 +115,43 @@ class TrainStep:
         self.optimizer.step()
         self.global_step += 1
         return total.detach()
+
+    def capture(self, images, masks, warmup=3):
+        """Capture forward + loss + backward + Adam into one HIP graph (the standard whole-step recipe of
+        torch.cuda.graphs: warm up on a side stream, capture with gradients set to None, replay on static inputs).
+
+        Everything inside the step is capture-safe: the renderer enqueues on the capturing stream and never synchronises,
+        allocates through torch's (graph-private) pool, draws the point dropout on the device, and the optimiser was built
+        with capturable=True.  What is frozen into the graph: the schedule values of THIS global_step (Gaussian sigma, dropout
+        keep-probability) -- recapture when they have moved noticeably -- and the shapes.  Returns replay(images, masks) ->
+        loss tensor (static memory, overwritten by the next replay)."""
+        if self.grad_sync is not None:
+            raise RuntimeError("capture() covers the single-process step; the overlapped gradient exchange runs eagerly")
+        if self.cfg.pc_point_dropout != 1 and not self.device_dropout:
+            raise RuntimeError("the reference's host-RNG point dropout uploads indices every step: not capturable; "
+                               "use device_dropout=True")
+        if not all(g["capturable"] for g in self.optimizer.param_groups):
+            raise RuntimeError("build the TrainStep with capturable=True")
+        static_images, static_masks = images.clone(), masks.clone()
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):          # lazy initialisations (Adam state, allocator, kernel attributes) happen here
+                self(static_images, static_masks)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        self.optimizer.zero_grad(set_to_none=True)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            total, _ = self.loss(static_images, static_masks)
+            total.backward()
+            self.optimizer.step()
+        self._graph, static_loss = graph, total.detach()
+
+        def replay(new_images, new_masks):
+            static_images.copy_(new_images)
+            static_masks.copy_(new_masks)
+            graph.replay()
+            self.global_step += 1
+            return static_loss
+
+        return replay

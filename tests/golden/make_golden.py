@@ -459,6 +459,29 @@ def f10_full_step():
     print("wrote f10_config.json; loss", float(loss), "winners", min_loss.tolist())
 
 
+def f12_view_sampler():
+    """ModelBase.preprocess (dpc/models/model_base_to.py:23-109): which views of which objects a step trains on, and the
+    tensors it selects.  Three cases on one set of raw inputs (3 objects x 5 views): random views, the first views in
+    order, and a variable number of views per object (one object has fewer views than the step needs: padded with view 0
+    and marked invalid).  The numpy RNG is seeded right before every call; stored: the seed, the raw inputs, the outputs."""
+    import models.model_base_to as ref_base
+
+    g = torch.Generator().manual_seed(1201)
+    raw = dict(image=torch.rand(3, 5, 3, 8, 8, generator=g), mask=(torch.rand(3, 5, 1, 8, 8, generator=g) > 0.5).float(),
+               extrinsic=torch.randn(3, 5, 4, 4, generator=g), cam_pos=torch.randn(3, 5, 3, generator=g),  # torch: the
+               # reference's select_2d (list-of-index-arrays) no longer means the same thing on numpy-2 arrays
+               num_views=torch.tensor([[5.0], [1.0], [3.0]]))
+    arrays = dict(image=raw["image"], mask=raw["mask"], extrinsic=raw["extrinsic"], num_views=raw["num_views"], seed=np.array(1202))
+    for tag, var, rnd in (("random", False, True), ("ordered", False, False), ("variable", True, True)):
+        cfg = make_cfg(batch_size=3, step_size=2, num_views_to_use=-1, variable_num_views=var, saved_depth=False, saved_camera=True)
+        np.random.seed(1202)
+        with quiet():
+            out = ref_base.ModelBase(cfg).preprocess(raw, cfg.step_size, random_views=rnd)
+        for k in ("images", "masks", "valid_samples", "images_1", "matrices"):
+            arrays[tag + "/" + k] = out[k]
+    save("f12_view_sampler.npz", **arrays)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     if len(sys.argv) > 1:  # regenerate only the named groups, e.g. `make_golden.py f11_nearest`
@@ -476,4 +499,5 @@ if __name__ == "__main__":
     f8_f9_model_side()
     f11_nearest()
     f10_full_step()
+    f12_view_sampler()
     assert not os.path.exists(os.path.join(REF, "dpc/util/__pycache__")), "left bytecode in the reference"
