@@ -45,7 +45,8 @@ __device__ inline void zcol_fwd_epilogue(const DpcParams& P, const RayConst& rc,
   if (live) {
     const int yrow = ray / P.W, x = ray - yrow * P.W;
     const int pix = (P.H - 1 - yrow) * P.W + x;
-    const float pr = (float)(1.0 - trans + (double)rc.em1 * (double)y0);
+    float pr = (float)(1.0 - trans + (double)rc.em1 * (double)y0);
+    if (!(fabsf(rc.s) <= 3.4e38f)) pr = __builtin_nanf("");  // NaN / infinite scale: NaN silhouette, like the reference's clamps
     proj[(size_t)b * HW + pix] = pr;
     if (trans_out != nullptr) trans_out[(size_t)b * HW + ray] = (float)trans;
     if (la.gt != nullptr) {
@@ -119,7 +120,7 @@ template <int DD, int RB, int RPL>
 __global__ __launch_bounds__(kColThreads, (RPL * DD <= 128 ? 2 : 1))
 void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, const float* __restrict__ s, TapsT<RB> taps,
                    TapsT<RB> taps_adj, float* __restrict__ proj, float* __restrict__ dT, float* __restrict__ ds_part,
-                   int n_ds_part, unsigned long long* __restrict__ tickets, int batch_frac, float* __restrict__ dsmall,
+                   int n_ds_part, unsigned long long* __restrict__ tickets, SseFormat cf, SseFormat bf, float* __restrict__ dsmall,
                    unsigned int* __restrict__ cg_count, LossArgs la) {
   typedef float vec __attribute__((ext_vector_type(RPL)));
   const int HW = P.H * P.W;
@@ -176,6 +177,9 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
     vec pr;
 #pragma unroll
     for (int r = 0; r < RPL; ++r) pr[r] = (float)(1.0 - tr[r] + (double)rc.em1 * (double)yfirst[r]);
+    if (!(fabsf(rc.s) <= 3.4e38f))  // a NaN or infinite occupancy scale: the reference's clamps hand the NaN on, med3 would not
+#pragma unroll
+      for (int r = 0; r < RPL; ++r) pr[r] = __builtin_nanf("");
     *reinterpret_cast<vec*>(proj + (size_t)b * HW + pix) = pr;
     if (DPC_ABL(17)) return;  // diagnostic: forward only
     const vec gtv = *reinterpret_cast<const vec*>(la.gt + (size_t)b * HW + pix);  // K == 1: sample == cloud
@@ -191,7 +195,7 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
   // 3.4 us here (device-scope atomics execute memory-side, ~7 ns apiece on one address, and the issuing wave's stores
   // queue behind them), and a release/acquire hand-over between blocks costs an L2 write-back per block (the eight
   // XCD L2s are not coherent with each other).  So each block makes ONE relaxed 64-bit atomic add to its cloud's word:
-  // the squared error in fixed point (kSseFrac fractional bits) plus a block count in the top bits.  The returned value
+  // the squared error in fixed point plus a block count above it (SseFormat in dpc_kernels.h).  The returned value
   // is looked at only after the backward half; whoever drew the last ticket holds the cloud's complete sum -- exact
   // integer adds, so sse[b] does not depend on the order the blocks arrived in -- and makes the cloud's single add
   // to the loss.
@@ -203,7 +207,7 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
   if (threadIdx.x == 0) {
     float tot = 0.f;
     for (int i = 0; i < kColThreads / DPC_WAVE; ++i) tot += red[0][i];
-    mine = (1ull << kSseCountShift) | (unsigned long long)((double)tot * (double)(1ull << kSseFrac) + 0.5);
+    mine = sse_share(cf, (double)tot, (double)kTileSseCap);
     before = __hip_atomic_fetch_add(tickets + b, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (live) {
@@ -258,21 +262,15 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
     for (int i = 0; i < kColThreads / DPC_WAVE; ++i) dst += red[1][i];
     // k_gather_hw sums n_ds_part partials per cloud (one per kColThreads rays); with RPL > 1 this grid has fewer blocks
     for (int i = bk.x; i < n_ds_part; i += bk.nx) ds_part[(size_t)b * n_ds_part + i] = i == bk.x ? dst : 0.f;
-    if ((int)(before >> kSseCountShift) == bk.nx - 1) {  // every other block of this cloud has added its share
-      const unsigned long long sum = (before + mine) & ((1ull << kSseCountShift) - 1);
-      const float tot = (float)((double)sum * (1.0 / (double)(1ull << kSseFrac)));
-      la.sse[b] = tot;
-      // The batch loss the same way, one level up: the clouds' exact sums go into one more 64-bit word (count in the top 16
-      // bits, batch_frac fractional bits chosen on the host so that B * H * W fits), and the cloud that arrives last writes
-      // the loss -- integer adds again, so the loss is bit-identical from run to run (float atomics here differed in the
-      // last bits with the arrival order).
-      const unsigned long long cmine =
-          (1ull << 48) | (unsigned long long)((double)sum * (1.0 / (double)(1ull << kSseFrac)) * (double)(1ull << batch_frac) + 0.5);
+    if (sse_complete(cf, before, bk.nx)) {  // every other block of this cloud has added its share
+      const double tot = sse_total(cf, before + mine);   // NaN if any tile's share was not a representable number
+      la.sse[b] = (float)tot;
+      // The batch loss the same way, one level up: the clouds' exact sums go into one more 64-bit word and the cloud that
+      // arrives last writes the loss -- integer adds again, so the loss is bit-identical from run to run (float atomics
+      // here differed in the last bits with the arrival order).
+      const unsigned long long cmine = sse_share(bf, tot, (double)kTileSseCap * bk.nx);
       const unsigned long long cbefore = __hip_atomic_fetch_add(tickets + bk.ny, cmine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((int)(cbefore >> 48) == bk.ny - 1) {
-        const unsigned long long total = (cbefore + cmine) & ((1ull << 48) - 1);
-        *la.loss_direct = (float)((double)total * (1.0 / (double)(1ull << batch_frac)) * (double)la.inv_S);
-      }
+      if (sse_complete(bf, cbefore, bk.ny)) *la.loss_direct = (float)(sse_total(bf, cbefore + cmine) * (double)la.inv_S);
     }
   }
   if (bk.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)threadIdx.x * bk.ny + b] = 0.f;  // [col][B]
@@ -489,16 +487,14 @@ int launch_zcol_fwdbwd(const DpcParams* p, const float* host_kern_z, const TapPl
   const RayHost rh = ray_host(p);
   constexpr int kRpl = DPC_ZFB_RPL;
   dim3 gpair(((p->H * p->W / kRpl + kColThreads - 1) / kColThreads) * p->B);
-  // fractional bits of the batch word: the batch's squared error is below B * H * W * 1.0001 and must stay below 2^48
-  int batch_frac = 46;
-  for (double cap = (double)p->B * p->H * p->W * 1.001 + 1.0; cap > 1.0; cap *= 0.5) --batch_frac;
-  if (batch_frac < 0) batch_frac = 0;
+  // field layouts of the per-cloud words (contributors: ray tiles) and of the batch word (contributors: clouds)
+  const SseFormat cf = sse_format(gpair.x / p->B, kTileSseCap), bf = sse_format(p->B, (double)kTileSseCap * (gpair.x / p->B));
 #define DPC_ZFB(RB)                                                                                                \
   {                                                                                                                \
     const TapsT<RB> tzf = make_taps<RB>(host_kern_z, pz, false), tza = make_taps<RB>(host_kern_z, pz, true);       \
-    if (p->D == 32) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<32, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, batch_frac, bwd_dsmall, cg_count, la); \
-    else if (p->D == 64) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<64, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, batch_frac, bwd_dsmall, cg_count, la); \
-    else DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<128, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, batch_frac, bwd_dsmall, cg_count, la); \
+    if (p->D == 32) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<32, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, cf, bf, bwd_dsmall, cg_count, la); \
+    else if (p->D == 64) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<64, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, cf, bf, bwd_dsmall, cg_count, la); \
+    else DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<128, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, cf, bf, bwd_dsmall, cg_count, la); \
   }
   DPC_FOR_BUCKET(pz.bucket, DPC_ZFB)
 #undef DPC_ZFB

@@ -7,6 +7,8 @@
 #include <math.h>
 #include <string.h>
 
+#include <atomic>
+
 #include "dpc_common.h"
 #include "dpc_profile.h"
 
@@ -41,9 +43,44 @@ namespace dpck {
 constexpr int kSlabThreads = 1024;
 constexpr int kColThreads = 256;
 constexpr int kNumCUs = 256;  // MI355X
-// k_zcol_fwdbwd's per-cloud word: [63:51] blocks arrived, [50:0] squared error, 30 fractional bits (a cloud's sum is
-// at most H*W <= 2^20)
-constexpr int kSseCountShift = 51, kSseFrac = 30;
+// k_zcol_fwdbwd's sum-and-count words (one per cloud, one for the batch), laid out for the launch at hand:
+//   [ poison | arrivals | squared error in fixed point ]
+// arrivals: ray tiles of a cloud / clouds of the batch, `bits` wide; poison: the same width above it -- a contributor whose
+// share is not a finite number inside the representable range adds 1 THERE instead of a sum (so a NaN scale, or a `gt`
+// that is no mask, surfaces as a NaN loss like in the reference, instead of silently corrupting the arrival count);
+// the sum field takes the rest.  A tile's share is at most 256 rays x 16 (|gt - proj| <= 4).
+struct SseFormat {
+  int frac;    // fractional bits of the sum field
+  int cshift;  // first bit of the arrival field (= width of the sum field)
+  int bits;    // width of the arrival field and of the poison field above it
+};
+constexpr float kTileSseCap = 4096.0f;
+inline int bit_width(unsigned long long v) {
+  int n = 0;
+  while (v) { ++n; v >>= 1; }
+  return n;
+}
+inline SseFormat sse_format(unsigned long long contributors, double max_share) {
+  SseFormat f;
+  f.bits = bit_width(contributors);                     // arrivals 0 .. contributors
+  f.cshift = 64 - 2 * f.bits;
+  const int int_bits = bit_width((unsigned long long)(contributors * max_share) + 1);
+  f.frac = f.cshift - int_bits;
+  if (f.frac > 30) f.frac = 30;
+  if (f.frac < 0) f.frac = 0;
+  return f;
+}
+__device__ inline unsigned long long sse_share(const SseFormat& f, double value, double cap) {
+  const bool bad = !(value >= 0.0 && value <= cap);     // NaN fails both comparisons
+  return (1ull << f.cshift) | (bad ? (1ull << (f.cshift + f.bits)) : (unsigned long long)(value * (double)(1ull << f.frac) + 0.5));
+}
+__device__ inline bool sse_complete(const SseFormat& f, unsigned long long before, int contributors) {
+  return (int)((before >> f.cshift) & ((1ull << f.bits) - 1ull)) == contributors - 1;
+}
+__device__ inline double sse_total(const SseFormat& f, unsigned long long word) {  // NaN when any contributor poisoned it
+  if ((word >> (f.cshift + f.bits)) != 0ull) return __longlong_as_double(0x7ff8000000000000ll);
+  return (double)(word & ((1ull << f.cshift) - 1ull)) * (1.0 / (double)(1ull << f.frac));
+}
 #ifndef DPC_ZFB_RPL
 #define DPC_ZFB_RPL 1  // rays per lane in k_zcol_fwdbwd (1 or 2)
 #endif
@@ -579,12 +616,23 @@ inline int planes_fit(const DpcParams* p) { return kLdsBudget / ((p->H * (p->W |
 inline int slab_threads(const DpcParams* p) { return (long long)p->H * p->W >= 2048 ? kSlabThreads : 256; }
 inline int col_tiles(const DpcParams* p) { return (p->H * p->W + kColThreads - 1) / kColThreads; }
 
+// Raise a kernel's dynamic-LDS limit.  hipFuncSetAttribute is a driver call, so it is made once per kernel, device and
+// size instead of on every launch: every launcher keeps, per device, the largest size it has set (relaxed atomics: two
+// threads racing on the first launch both make the call, which is idempotent).  `slot` is a static of the launcher's
+// template instantiation = one per kernel.
+struct LdsLimit {
+  std::atomic<size_t> set[16];
+};
 template <class K>
-int set_lds(K kernel, size_t bytes) {
-  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)bytes) == hipSuccess
-             ? DPC_OK
-             : DPC_ERR_LAUNCH;
+int set_lds(K kernel, size_t bytes, LdsLimit& slot) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return DPC_ERR_LAUNCH;
+  const bool tracked = dev >= 0 && dev < 16;
+  if (tracked && slot.set[dev].load(std::memory_order_relaxed) >= bytes) return DPC_OK;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess)
+    return DPC_ERR_LAUNCH;
+  if (tracked) slot.set[dev].store(bytes, std::memory_order_relaxed);
+  return DPC_OK;
 }
 
 inline RayHost ray_host(const DpcParams* p) {

@@ -2,6 +2,7 @@
 // an explicit enable call, never touched otherwise.
 #include "dpc_profile.h"
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/dpc_render.h"
@@ -11,6 +12,7 @@ struct Slot {
   const char* name;
   hipEvent_t a, b;
 };
+std::mutex g_mu;  // launches may come from torch's autograd thread while the caller reads results
 bool g_on = false;
 std::vector<Slot> g_slots;
 size_t g_used = 0;
@@ -18,6 +20,8 @@ bool g_open = false;
 }  // namespace
 
 void dpc_prof_before(const char* name, hipStream_t st) {
+  if (!g_on) return;  // the common case takes no lock
+  std::lock_guard<std::mutex> lock(g_mu);
   if (!g_on || g_used >= g_slots.size()) return;
   g_slots[g_used].name = name;
   (void)hipEventRecord(g_slots[g_used].a, st);
@@ -25,6 +29,8 @@ void dpc_prof_before(const char* name, hipStream_t st) {
 }
 
 void dpc_prof_after(hipStream_t st) {
+  if (!g_on) return;
+  std::lock_guard<std::mutex> lock(g_mu);
   if (!g_on || !g_open) return;
   (void)hipEventRecord(g_slots[g_used].b, st);
   ++g_used;
@@ -35,6 +41,7 @@ extern "C" {
 
 int dpc_profile_enable(int capacity) {
   if (capacity < 0) return DPC_ERR_SHAPE;
+  std::lock_guard<std::mutex> lock(g_mu);
   while ((int)g_slots.size() < capacity) {
     Slot s{nullptr, nullptr, nullptr};
     if (hipEventCreate(&s.a) != hipSuccess || hipEventCreate(&s.b) != hipSuccess) return DPC_ERR_LAUNCH;
@@ -47,6 +54,7 @@ int dpc_profile_enable(int capacity) {
 }
 
 int dpc_profile_disable(void) {
+  std::lock_guard<std::mutex> lock(g_mu);
   g_on = false;
   return DPC_OK;
 }

@@ -291,7 +291,8 @@ int launch_gather_fast(const DpcParams* p, Cells cells, const float* pc, const f
   static_assert(lds <= kLdsLimit, "backward slab does not fit LDS");
   static_assert(kRedTab >= 13 * (Geo::NT / DPC_WAVE) && kRedMask >= kRedTab + kTabInts, "scratch tail layout");
   auto kern = k_gather_hw<GS, ZS, RB>;
-  int rc = set_lds(kern, lds);
+  static LdsLimit limit;
+  int rc = set_lds(kern, lds, limit);
   if (rc != DPC_OK) return rc;
   // one-layer slabs roll over several layers per workgroup (see the kernel): as many as still leave a workgroup per CU
   int roll = 1;
@@ -325,7 +326,8 @@ int launch_gather_rb(const DpcParams* p, Cells cells, const float* pc, const flo
   const int Zs = std::min(fit - 1, std::max(1, (p->D + 7) / 8));
   const size_t lds = ((size_t)(Zs + 1) * p->H * (p->W | 1) + kRedFloats) * sizeof(float);
   auto kern = k_gather_hw<0, 0, RB>;
-  int rc = set_lds(kern, lds);
+  static LdsLimit limit;
+  int rc = set_lds(kern, lds, limit);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_gather_hw", kern, dim3(((p->D + Zs - 1) / Zs) * p->B), dim3(slab_threads(p)), lds, st, *p, cells, pc, q, t, f,
              make_taps<RB>(kxy, pxy, true), Zs, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la);

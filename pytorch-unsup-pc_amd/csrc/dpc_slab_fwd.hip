@@ -350,7 +350,8 @@ int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const T
   static_assert(lds >= Geo::slab_floats(ZS) * sizeof(float), "the fp32 slab reuses the accumulator memory");
   static_assert(lds <= kLdsLimit, "forward slab does not fit LDS");
   auto kern = k_splat_hw<GS, ZS, RB>;
-  int rc = set_lds(kern, lds);
+  static LdsLimit limit;
+  int rc = set_lds(kern, lds, limit);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_splat_hw", kern, dim3(((p->D + ZS - 1) / ZS) * p->B), dim3(Geo::NT), lds, st, *p, cells,
              make_taps<RB>(kxy, pxy, false), ZS, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
@@ -381,7 +382,8 @@ int launch_splat_rb(const DpcParams* p, Cells cells, const float* kxy, const Tap
   const int Zs = std::min(fit, std::max(1, (p->D + 7) / 8));
   const size_t lds = (size_t)Zs * p->H * (p->W | 1) * sizeof(float);
   auto kern = k_splat_hw<0, 0, RB>;
-  int rc = set_lds(kern, lds);
+  static LdsLimit limit;
+  int rc = set_lds(kern, lds, limit);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_splat_hw", kern, dim3(((p->D + Zs - 1) / Zs) * p->B), dim3(slab_threads(p)), lds, st, *p, cells,
              make_taps<RB>(kxy, pxy, false), Zs, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);

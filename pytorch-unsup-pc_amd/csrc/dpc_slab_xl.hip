@@ -197,7 +197,8 @@ int launch_splat_xl_zr(const DpcParams* p, Cells cells, const float* kxy, const 
   constexpr size_t lds = (size_t)ZS * (kXG + 2 * RB) * kXG * sizeof(unsigned long long) + kTabInts * sizeof(int);
   static_assert(lds <= kLdsLimit, "forward slab does not fit LDS");
   auto kern = k_splat_xl<ZS, RB>;
-  int rc = set_lds(kern, lds);
+  static LdsLimit limit;
+  int rc = set_lds(kern, lds, limit);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_splat_hw", kern, dim3(((p->D + ZS - 1) / ZS) * p->B), dim3(ZS * 256), lds, st, *p, cells,
              make_taps<RB>(kxy, pxy, false), Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
@@ -374,7 +375,8 @@ int launch_gather_xl_zr(const DpcParams* p, Cells cells, const float* q, const f
   constexpr size_t lds = (size_t)(ZS + 1) * kXG * kXG * sizeof(float) + kTabInts * sizeof(int) + camgrad_scratch_bytes(kSlabThreads);
   static_assert(lds <= kLdsLimit, "backward slab does not fit LDS");
   auto kern = k_gather_xl<ZS, RB>;
-  int rc = set_lds(kern, lds);
+  static LdsLimit limit;
+  int rc = set_lds(kern, lds, limit);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_gather_hw", kern, dim3(((p->D + ZS - 1) / ZS) * p->B), dim3(kSlabThreads), lds, st, *p, cells, q, t, f,
              make_taps<RB>(kxy, pxy, true), dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la);

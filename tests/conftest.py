@@ -18,13 +18,19 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def native_library():
-    """The tests bind libdpc_render.so; a checkout that has not been built yet is built here (hipcc cross-compiles for
-    gfx950 without a GPU, a few minutes) instead of failing on the first test that loads it."""
+    """The tests bind libdpc_render.so; a checkout that has not been built yet -- or whose library is older than a source
+    it is built from -- is (re)built here (hipcc cross-compiles for gfx950 without a GPU, a few minutes) instead of failing
+    on the first test that loads it, or passing on stale kernels."""
     lib = os.path.join(PKG, "csrc", "libdpc_render.so")
-    if not os.path.exists(lib) and os.path.exists("/opt/rocm/bin/hipcc"):
+    csrc = os.path.join(PKG, "csrc")
+    sources = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")) or f == "Makefile"]
+    sources.append(os.path.join(ROOT, "include", "dpc_render.h"))
+    stale = os.path.exists(lib) and any(os.path.getmtime(f) > os.path.getmtime(lib) for f in sources)
+    if (stale or not os.path.exists(lib)) and os.path.exists("/opt/rocm/bin/hipcc"):
         import subprocess
 
-        subprocess.run(["make", "-C", os.path.join(PKG, "csrc"), "-j3"], check=True, stdout=subprocess.DEVNULL)
+        # a library older than its sources would be tested silently (same ABI number, different kernels): make decides
+        subprocess.run(["make", "-C", csrc, "-j3"], check=True, stdout=subprocess.DEVNULL)
     return lib
 
 

@@ -449,6 +449,30 @@ def test_benchmarked_call_at_full_size(R, O):
     close(ds[idx], cs.grad, TOL, "benchmarked call: ds vs oracle")
 
 
+def test_fused_loss_does_not_hide_divergence(R, O):
+    """A non-finite occupancy scale (a diverged network) or a `gt` that is no mask must surface as a NaN loss, as the
+    reference's float sum would report it -- the fused loss sums in 64-bit fixed point, where such a share is flagged in a
+    field of its own instead of being converted to an integer.  The next (clean) call is unaffected."""
+    B, N, G = 4, 900, 32
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 8800)
+    kern = R.smoothing_kernel(cfg, 1.0)
+
+    def run(scale, mask):
+        gp, gq, gs = dev(pc, True), dev(q, True), dev(scale, True)
+        loss, _, _ = R.pointcloud_project_loss(cfg, gp, gq, None, None, kern, scaling_factor=gs, gt=dev(mask), num_candidates=1)
+        loss.backward()
+        return float(loss.detach())
+
+    clean = run(s, gt)
+    assert np.isfinite(clean)
+    bad_s = s.clone()
+    bad_s[1] = float("nan")
+    assert np.isnan(run(bad_s, gt))
+    assert np.isnan(run(s, gt * 200.0))        # squared errors beyond the range of the fixed-point words
+    assert run(s, gt) == clean                 # the words start from zero again
+
+
 def test_silhouette_loss_candidates(R, O, golden):
     """Fused min-of-K loss + gradient vs proj_loss_pose_candidates of the reference (fixture F8), and K=1."""
     g = golden("f8_candidates.npz")

@@ -176,7 +176,7 @@ def test_config3_full_size(keep):
     # the fused loss equals the reference's formula on the silhouettes it returned (min over the K candidates per image)
     per = ((out["projs"].double().reshape(nimg, K, -1) - out["pooled_masks"].double().reshape(nimg, 1, -1)) ** 2).sum(-1)
     assert np.array_equal(per.argmin(1).cpu().numpy(), win)
-    assert abs(float(out["proj_loss"]) - float(per.min(1).values.sum() / nimg)) <= 1e-5 * float(out["proj_loss"])
+    assert abs(float(out["proj_loss"].detach()) - float(per.min(1).values.sum() / nimg)) <= 1e-5 * float(out["proj_loss"].detach())
     total.backward()
     named = dict(step.nets.named_parameters())
     assert named["decoder.pts_raw_fc.weight"].grad is not None and named["decoder.rgb_raw_dec.weight"].grad is None
