@@ -94,7 +94,7 @@ class OverlappedGradAllReduce:
     ordered after the producing kernels), while autograd carries on with the layers below.  `finish()` starts the
     buckets that never filled (parameters without gradient this step count as zeros, so every rank agrees on the
     layout), waits for all of them and detaches the parameters that received no gradient (`.grad = None`, which is
-    what the single-process run hands the optimiser).
+    what the single-process run hands the optimiser); after the FIRST step those parameters are dropped from the exchange.
 
         sync = OverlappedGradAllReduce(nets.parameters())
         sync.prepare(local_samples, total_samples); loss.backward(); sync.finish(); optimizer.step()
@@ -104,14 +104,22 @@ class OverlappedGradAllReduce:
     """
 
     def __init__(self, params, bucket_mb=32, group=None, overlap=True):
-        self.params = [p for p in params if p.requires_grad]
+        self.all_params = [p for p in params if p.requires_grad]
         self.group, self.overlap = group, overlap
-        limit = max(1, int(bucket_mb * (1 << 20)) // 4)
+        self._limit = max(1, int(bucket_mb * (1 << 20)) // 4)
+        self._events, self._host_exposed, self.steps = [], 0.0, 0
+        self._scale, self._armed, self._trimmed = 1.0, False, False
+        self._layout(self.all_params)
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.all_params]
+
+    def _layout(self, params):
+        """Flat buckets over `params` in reverse registration order; .grad views; arrival bookkeeping."""
+        self.params = list(params)
         self.buckets, cur, size = [], [], 0
         for p in reversed(self.params):
             cur.append(p)
             size += p.numel()
-            if size >= limit:
+            if size >= self._limit:
                 self.buckets.append(cur)
                 cur, size = [], 0
         if cur:
@@ -130,13 +138,10 @@ class OverlappedGradAllReduce:
             self.flat.append(flat)
         self.num_buckets = len(self.buckets)
         self.nbytes = sum(f.numel() * f.element_size() for f in self.flat)
-        self._expected = [len(b) for b in self.buckets]   # arrivals that complete a bucket; adapts after the first step
+        self._expected = [len(b) for b in self.buckets]
         self._arrived = [0] * self.num_buckets
         self._seen = set()
         self._work = [None] * self.num_buckets
-        self._scale, self._armed = 1.0, False
-        self._events, self._host_exposed, self.steps = [], 0.0, 0
-        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
 
     def _active(self):
         return dist.is_initialized() and dist.get_world_size(self.group) > 1
@@ -165,6 +170,9 @@ class OverlappedGradAllReduce:
     def _hook(self, p):
         if not self._armed:
             return
+        if id(p) not in self._bucket_of:
+            raise RuntimeError("a parameter that had no gradient in the first step has one now: the exchange was laid out "
+                               "without it (every rank drops the same gradient-less parameters after step one)")
         bi, view = self._bucket_of[id(p)], self.views[id(p)]
         if p.grad.data_ptr() != view.data_ptr():   # autograd replaced the view (it does when .grad was None)
             view.copy_(p.grad)
@@ -197,12 +205,22 @@ class OverlappedGradAllReduce:
         else:
             self._host_exposed += time.perf_counter() - t0
         self.steps += 1
-        # buckets fill only as far as gradients really arrive: learn that from this step (same on every rank, the
-        # graphs are the same), so that from the next step on every bucket goes out the moment its last gradient lands
-        self._expected = [a if a > 0 else len(b) for a, b in zip(self._arrived, self.buckets)]
         for p in self.params:
             if id(p) not in self._seen:
                 p.grad = None
+        # Parameters without a gradient (the reference's colour decoder and focal head are built but unused: 28 M of the 61 M
+        # parameters) took part as zeros in this first exchange, so that all ranks agreed on the layout; the autograd graph
+        # is the same on every rank and in every step, so from now on they are left out: less than half the bytes go over
+        # the wire, and every bucket is sent the moment its last gradient lands.
+        if not self._trimmed:
+            self._trimmed = True
+            alive = [p for p in self.params if id(p) in self._seen]
+            if alive and len(alive) < len(self.params):
+                grads = {id(p): p.grad.clone() for p in alive}
+                self._layout(alive)
+                for p in alive:
+                    self.views[id(p)].copy_(grads[id(p)])
+                    p.grad = self.views[id(p)]
         self._armed = False
 
     @property
