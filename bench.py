@@ -60,6 +60,7 @@ def kernel_bytes_per_cloud(n, g):
     return {
         "k_locate": 12 * n + cells,                       # read pc, write the binned records
         "k_splat_hw": 16 * n + 4 * g3 + g3 // 8,          # read records, write T (after W/H passes) + clamp mask
+        "k_splat_xl": 16 * n + 4 * g3 + g3 // 8,          # the same work, x-in-lanes kernel (64-wide grids, radius <= 6)
         "k_zcol_fwd": 4 * g3 + 4 * g2,                    # read T, write silhouette
         "k_zcol_bwd": 4 * g3 + 4 * g3 + 8 * g2,           # read T + dproj (or proj, gt), write dT
         "k_zcol_fwdbwd": 4 * g3 + 4 * g3 + 8 * g2,        # read T + gt, write dT + silhouette (column backward fused)
@@ -75,7 +76,7 @@ def step_bytes_per_cloud(n, g, k_cand):
     return fwd + bwd / k_cand
 
 
-PROFILE_SUMMARIES = ("r02_rocprof_summary.json", "r01_rocprof_summary.json")   # newest first
+PROFILE_SUMMARIES = ("r02_rocprof_summary.json", "r02_rocprof_summary_c4.json", "r01_rocprof_summary.json")   # newest first
 
 
 def measured_traffic(kernel, config="c2"):

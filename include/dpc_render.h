@@ -142,7 +142,10 @@ int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const f
  * accumulates each cloud's sum of squared differences, a one-block finalize picks argmin over K (first minimum)
  * and writes loss = sum_s min_k sse / S.  In the backward dproj = 2 (proj - gt) / S * dloss is formed on the fly
  * (never stored) and losing candidates skip all work -- their gradients are exact zeros.
- *   fwd outputs: proj [B,H,W], trans [B,H,W], sse [B], loss [1], winner [B/K] int32 (+ tr_pc|NULL, cells, grid_wh, mask)
+ *   fwd outputs: proj [B,H,W], trans [B,H,W], sse [B], loss [1], winner [B/K] int32 (+ tr_pc|NULL, cells, grid_wh, mask);
+ *                sse_tiles [B, ceil(H*W/256)] scratch: the ray tiles' squared errors, added in tile order by the finalize
+ *                launch (no float atomics: sums, winners and loss are the same bits on every run); may be NULL only when
+ *                the column backward is fused into the forward (see below), which sums in 64-bit fixed point instead
  *   bwd inputs : dloss = device scalar arriving at `loss` (NULL = 1)
  *
  * Column half of the backward inside the forward (optional): d loss / d proj is linear in dloss, and the forward's
@@ -154,8 +157,8 @@ int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const f
 int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                          const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt,
                          int num_candidates, float* tr_pc, void* cells, float* grid_wh, uint64_t* mask, float* proj,
-                         float* trans, float* sse, float* loss, int32_t* winner, void* bwd_workspace, float* bwd_dsmall,
-                         int* column_backward_done, void* stream);
+                         float* trans, float* sse, float* sse_tiles, float* loss, int32_t* winner, void* bwd_workspace,
+                         float* bwd_dsmall, int* column_backward_done, void* stream);
 int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                          const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
                          const float* grid_wh, const uint64_t* mask, const float* proj, const float* trans,

@@ -8,16 +8,23 @@ DPC_DEBUG_SETTERS(col)
 namespace dpck {
 namespace {
 
-__global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ sse, int S, int K, float inv_S,
-                                                       float* __restrict__ loss, int* __restrict__ winner) {
+// The unfused ray march leaves one squared-error partial per (cloud, ray tile); here they are added in tile order (so the
+// clouds' sums, the winners and the loss are the same bits on every run), the best pose candidate of every sample is
+// picked and the loss formed.  One block.
+__global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ sse_tiles, int ntile, float* __restrict__ sse,
+                                                       int S, int K, float inv_S, float* __restrict__ loss,
+                                                       int* __restrict__ winner) {
   __shared__ float red[256 / DPC_WAVE];
   float acc = 0.f;
   for (int smp = threadIdx.x; smp < S; smp += blockDim.x) {
-    float best = sse[(size_t)smp * K];
+    float best = 0.f;
     int bk = 0;
-    for (int k = 1; k < K; ++k) {
-      const float v = sse[(size_t)smp * K + k];
-      if (v < best) { best = v; bk = k; }  // first minimum wins, like torch.argmin
+    for (int k = 0; k < K; ++k) {
+      const size_t cloud = (size_t)smp * K + k;
+      float v = 0.f;
+      for (int i = 0; i < ntile; ++i) v += sse_tiles[cloud * ntile + i];
+      sse[cloud] = v;
+      if (k == 0 || v < best) { best = v; bk = k; }  // first minimum wins, like torch.argmin
     }
     winner[smp] = bk;
     acc += best;
@@ -37,10 +44,10 @@ __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__
 // ------------------------------------------------------------------------------------------------------
 // Epilogue shared by the forward column kernels: silhouette (row flip folded into the index), saved ray
 // transmittance, fused loss partial.
-__device__ inline void zcol_fwd_epilogue(const DpcParams& P, const RayConst& rc, int b, int ray, bool live, double trans,
+__device__ inline void zcol_fwd_epilogue(const DpcParams& P, const RayConst& rc, const Blk& bk, int ray, bool live, double trans,
                                          float y0, float* __restrict__ proj, float* __restrict__ trans_out,
                                          const LossArgs& la) {
-  const int HW = P.H * P.W;
+  const int HW = P.H * P.W, b = bk.y;
   float sq = 0.f;
   if (live) {
     const int yrow = ray / P.W, x = ray - yrow * P.W;
@@ -62,8 +69,7 @@ __device__ inline void zcol_fwd_epilogue(const DpcParams& P, const RayConst& rc,
     if (threadIdx.x == 0) {
       float tot = 0.f;
       for (int i = 0; i < kColThreads / DPC_WAVE; ++i) tot += red[i];
-      atomicAdd(la.sse + b, tot);
-      if (la.loss_direct != nullptr) atomicAdd(la.loss_direct, tot * la.inv_S);  // K == 1: every cloud wins
+      la.sse_tiles[(size_t)b * bk.nx + bk.x] = tot;  // no atomics: k_loss_finalize adds the tiles in order
     }
   }
 }
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_fwd(Dp
       trans *= 1.0 - (double)y;
     }
   }
-  zcol_fwd_epilogue(P, rc, b, ray, live, trans, y0, proj, trans_out, la);
+  zcol_fwd_epilogue(P, rc, bk, ray, live, trans, y0, proj, trans_out, la);
 }
 
 // Forward 2 + Backward 1 in one launch (fused loss, one pose candidate per sample): the gradient arriving at the
@@ -116,8 +122,11 @@ __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_fwd(Dp
 //   y = med3(s v2, eps, 1-eps)  [= the reference's clamp(clamp(s v2, 0, 1), eps, 1-eps)],  inside <=> y == s v2
 //   dL/dv3 = g T / (1 - y) (+ g (e^eps - 1) for the first voxel),  dL/ds = sum y dL/dv3 / s  (inside: v2 = y / s)
 // RPL = rays per lane: neighbouring rays x .. x+RPL-1 (RPL divides W, so they share an image row).
+#ifndef DPC_ZFB_2WAVE_MAX
+#define DPC_ZFB_2WAVE_MAX 128  // deepest column that is compiled for two waves per SIMD (256 VGPRs per lane)
+#endif
 template <int DD, int RB, int RPL>
-__global__ __launch_bounds__(kColThreads, (RPL * DD <= 128 ? 2 : 1))
+__global__ __launch_bounds__(kColThreads, (RPL * DD <= DPC_ZFB_2WAVE_MAX ? 2 : 1))
 void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, const float* __restrict__ s, TapsT<RB> taps,
                    TapsT<RB> taps_adj, float* __restrict__ proj, float* __restrict__ dT, float* __restrict__ ds_part,
                    int n_ds_part, unsigned long long* __restrict__ tickets, SseFormat cf, SseFormat bf, float* __restrict__ dsmall,
@@ -310,7 +319,7 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_fwd_dyn(DpcParams P, RayHo
       trans *= 1.0 - (double)y;
     }
   }
-  zcol_fwd_epilogue(P, rc, b, ray, live, trans, y0, proj, trans_out, la);
+  zcol_fwd_epilogue(P, rc, bk, ray, live, trans, y0, proj, trans_out, la);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -549,8 +558,9 @@ int launch_zcol_bwd(const DpcParams* p, const float* host_kern_z, const TapPlan&
   return launch_ok();
 }
 
-int launch_loss_finalize(const float* sse, int S, int K, float inv_S, float* loss, int32_t* winner, hipStream_t st) {
-  DPC_LAUNCH("k_loss_finalize", k_loss_finalize, dim3(1), dim3(256), 0, st, sse, S, K, inv_S, loss, winner);
+int launch_loss_finalize(const float* sse_tiles, int ntile, float* sse, int S, int K, float inv_S, float* loss, int32_t* winner,
+                         hipStream_t st) {
+  DPC_LAUNCH("k_loss_finalize", k_loss_finalize, dim3(1), dim3(256), 0, st, sse_tiles, ntile, sse, S, K, inv_S, loss, winner);
   return launch_ok();
 }
 

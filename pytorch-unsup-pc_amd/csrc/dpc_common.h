@@ -363,11 +363,20 @@ __host__ __device__ constexpr size_t camgrad_scratch_bytes(int nthr) { return (s
 // in fp64.  The order of every addition is fixed by the thread ids alone.  Returns value `tid`'s total in threads 0..12.
 // (A version that parked all 13 x nthr values in LDS and summed them in fp64 measured 0.7 us slower per workgroup and no
 // more accurate.)
-__device__ inline double block_sum13_fixed(const float (&vals)[13], float* scratch, int tid, int nthr) {
+// `nvals` (block-uniform) = 9 when neither a translation nor a focal length takes a gradient: the last four accumulators
+// (dt, df) are then not reduced at all (their totals read 0).
+__device__ inline double block_sum13_fixed(const float (&vals)[13], float* scratch, int tid, int nthr, int nvals = 13) {
   const int lane = tid & (DPC_WAVE - 1), wave = tid / DPC_WAVE, nw = nthr / DPC_WAVE;
   float ws[13];
 #pragma unroll
-  for (int i = 0; i < 13; ++i) ws[i] = wave_sum(vals[i]);
+  for (int i = 0; i < 9; ++i) ws[i] = wave_sum(vals[i]);
+  if (nvals > 9) {
+#pragma unroll
+    for (int i = 9; i < 13; ++i) ws[i] = wave_sum(vals[i]);
+  } else {
+#pragma unroll
+    for (int i = 9; i < 13; ++i) ws[i] = 0.f;
+  }
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < 13; ++i) scratch[wave * 13 + i] = ws[i];

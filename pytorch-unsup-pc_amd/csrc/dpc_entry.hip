@@ -116,7 +116,7 @@ int project_bwd_impl(const DpcParams* p, const float* pc, const float* q, const 
                        dsmall, w.cg_part, w.cg_count, la, st);
 }
 
-const LossArgs kNoLoss{nullptr, nullptr, nullptr, nullptr, 1, 1.0f, nullptr, nullptr, 0};
+const LossArgs kNoLoss{nullptr, nullptr, nullptr, nullptr, 1, 1.0f, nullptr, nullptr, 0, nullptr};
 
 }  // namespace
 
@@ -141,24 +141,24 @@ int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const f
 int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                          const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt,
                          int num_candidates, float* tr_pc, void* cells, float* grid_wh, uint64_t* mask, float* proj,
-                         float* trans, float* sse, float* loss, int32_t* winner, void* bwd_workspace, float* bwd_dsmall,
-                         int* column_backward_done, void* stream) {
+                         float* trans, float* sse, float* sse_tiles, float* loss, int32_t* winner, void* bwd_workspace,
+                         float* bwd_dsmall, int* column_backward_done, void* stream) {
   if (!p || !gt || !sse || !loss || !winner) return DPC_ERR_NULL;
   if (num_candidates < 1 || p->B % num_candidates != 0) return DPC_ERR_SHAPE;
   const int S = p->B / num_candidates;
-  const bool direct = num_candidates == 1;  // every cloud is its sample's winner: blocks add straight into the loss
-  const LossArgs la{gt, sse, nullptr, nullptr, num_candidates, S > 0 ? 1.0f / (float)S : 0.f,
-                    direct ? loss : nullptr, direct ? winner : nullptr, 0};
-  // the forward can also run the column half of the backward when there is one candidate per sample (see k_zcol_fwdbwd)
+  // one candidate per sample AND a backward workspace: the fused ray march sums the loss itself (64-bit fixed point)
   const TapPlan pz = plan_taps(host_kern_z, p->taps_z);
-  const bool fuse = direct && bwd_workspace && bwd_dsmall &&
+  const bool fuse = num_candidates == 1 && bwd_workspace && bwd_dsmall &&
                     can_fuse_column_backward(p, pz, num_candidates, grid_wh, proj, gt, bwd_workspace);
+  if (!fuse && !sse_tiles) return DPC_ERR_NULL;  // the unfused ray march leaves per-tile partials for the finalize launch
+  const LossArgs la{gt, sse, nullptr, nullptr, num_candidates, S > 0 ? 1.0f / (float)S : 0.f,
+                    fuse ? loss : nullptr, fuse ? winner : nullptr, 0, fuse ? nullptr : sse_tiles};
   if (column_backward_done) *column_backward_done = fuse ? 1 : 0;
   int rc = project_fwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, tr_pc, cells, nullptr, grid_wh, nullptr, mask,
                             proj, trans, la, fuse ? bwd_workspace : nullptr, fuse ? bwd_dsmall : nullptr,
                             (hipStream_t)stream);
-  if (rc != DPC_OK || p->B == 0 || direct) return rc;
-  return launch_loss_finalize(sse, S, num_candidates, la.inv_S, loss, winner, (hipStream_t)stream);
+  if (rc != DPC_OK || p->B == 0 || fuse) return rc;
+  return launch_loss_finalize(sse_tiles, col_tiles(p), sse, S, num_candidates, la.inv_S, loss, winner, (hipStream_t)stream);
 }
 
 int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
@@ -170,7 +170,7 @@ int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, co
   if (num_candidates < 1 || p->B % num_candidates != 0) return DPC_ERR_SHAPE;
   const int S = p->B / num_candidates;
   const LossArgs la{gt, nullptr, winner, dloss, num_candidates, S > 0 ? 1.0f / (float)S : 0.f, nullptr, nullptr,
-                    column_backward_done ? 1 : 0};
+                    column_backward_done ? 1 : 0, nullptr};
   return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, grid_wh, mask, nullptr, proj, trans, la,
                           dpc, dsmall, workspace, nullptr, (hipStream_t)stream);
 }

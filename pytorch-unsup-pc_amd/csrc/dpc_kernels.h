@@ -540,6 +540,7 @@ struct LossArgs {
   float* loss_direct;   // forward, K == 1 only: the scalar loss, accumulated by the ray-march blocks (no finalize launch)
   int* winner_out;      // forward, K == 1 only: zero-filled by k_splat_hw
   int scale_in_gather;  // backward: dT was produced by the forward for dloss = 1; k_gather_hw multiplies by *dloss
+  float* sse_tiles;     // forward, unfused ray march: [B, tiles] per-tile squared errors, summed in tile order by k_loss_finalize
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -569,7 +570,7 @@ inline TapPlan plan_taps(const float* k, int taps) {
     --r;
   }
   p.radius = r;
-  static const int buckets[] = {0, 1, 2, 3, 4, 6, 10, 15};
+  static const int buckets[] = {0, 1, 2, 3, 4, 6, 8, 10, 15};   // 8: sigma = 0.01 world units on a 128^3 grid (sigma_rel 1.28)
   p.bucket = -1;
   for (int bk : buckets)
     if (r <= bk) {
@@ -654,6 +655,7 @@ inline Cells cells_view(const DpcParams* p, const void* cells) {
     case 3: MACRO(3); break;          \
     case 4: MACRO(4); break;          \
     case 6: MACRO(6); break;          \
+    case 8: MACRO(8); break;          \
     case 10: MACRO(10); break;        \
     case 15: MACRO(15); break;        \
     default: rc = DPC_ERR_TAPS;       \
@@ -708,11 +710,9 @@ inline Workspace workspace_view(const DpcParams* p, void* ws) {
 
 // ------------------------------------------------------------------------------------------------------
 // Camera gradient of a cloud (dq, dt, df): 13 sums over the cloud's points, taken in a FIXED order so that the result
-// is the same bits on every run (float atomics between the slab workgroups made dq/dt/df vary in the last places), and in
-// fp64 from the per-thread values on (the fp32 tree it replaces cost a third of the d(q) parity margin).
-//   block_sum13_fixed  every thread parks its 13 values in LDS, value-major; 13 x 16 threads each add a stride-16 comb
-//                      of one value (the lanes of a comb group read consecutive words: conflict-free); 13 threads add
-//                      the 16 comb sums.  Also ~4x cheaper than 13 DPP wave reductions + the cross-wave pass.
+// is the same bits on every run (float atomics between the slab workgroups made dq/dt/df vary in the last places), in fp64
+// from the wave totals on.
+//   block_sum13_fixed  per wave a DPP butterfly (fp32, a fixed tree), then the wave totals in wave order in fp64 (dpc_common.h)
 //   camgrad_publish    the slab workgroups of a cloud hand their sums over INSIDE the launch: write-through (sc1) stores
 //                      of the 13 doubles, the storing wave's vmcnt(0), one agent-scope ticket add; the workgroup that
 //                      drew the last ticket reads all slabs' sums with sc1 loads in slab order, turns the moment matrix
@@ -720,7 +720,6 @@ inline Workspace workspace_view(const DpcParams* p, void* ws) {
 //                      measured valid on gfx950 ("Valid forms", first table row: one lane's agent-scope add as the signal,
 //                      the last adder told by the returned value, all handed-off bytes stored and loaded sc1); no L2
 //                      write-back, no acquire.  The counter is left at zero again for the next backward.
-// scratch: 13 * nthr floats + 208 doubles of LDS nobody else is using (callers pass the dead slab, behind a barrier).
 // ------------------------------------------------------------------------------------------------------
 // tot: this slab's sum of accumulator `tid` (threads 0..12, from block_sum13_fixed).  Called by the whole first wave.
 __device__ inline void camgrad_publish(double tot, int tid, const CameraRaw& raw, int B, int b, int slab, int nslab,
@@ -779,7 +778,8 @@ int launch_zcol_fwdbwd(const DpcParams* p, const float* host_kern_z, const TapPl
 int launch_zcol_bwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* grid_wh, const float* s,
                     const float* dproj, const float* proj, const float* trans, float* dT, float* ds_part, float* dsmall,
                     unsigned int* cg_count, const float* dgrid_extra, const LossArgs& la, hipStream_t st);
-int launch_loss_finalize(const float* sse, int S, int K, float inv_S, float* loss, int32_t* winner, hipStream_t st);
+int launch_loss_finalize(const float* sse_tiles, int ntile, float* sse, int S, int K, float inv_S, float* loss, int32_t* winner,
+                         hipStream_t st);
 // dpc_slab_xl.hip: the x-in-lanes slab kernels (64 x 64 planes, radius bucket 1..6); DPC_NO_XL builds keep the older kernels
 bool xl_applies(const DpcParams* p, int bucket);
 int launch_splat_xl(int bucket, const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* Tbuf, uint64_t* mask,

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   for (int i = 0; i < 9; ++i) vals[i] = g.m[i];
   vals[9] = g.dt[0]; vals[10] = g.dt[1]; vals[11] = g.dt[2]; vals[12] = g.df;
   if (DPC_ABL(13)) { if (vals[0] == 123.f) dsmall[0] = vals[1]; return; }
-  const double tot = block_sum13_fixed(vals, red, tid, nthr);
+  const double tot = block_sum13_fixed(vals, red, tid, nthr, (t != nullptr || f != nullptr) ? 13 : 9);
   DPC_STAMP(12);
   if (tid == 0 && bk.x == 0) {  // the occupancy-scale gradient: the column kernel's per-tile partials, in tile order
     float ds = 0.f;

@@ -200,7 +200,7 @@ int launch_splat_xl_zr(const DpcParams* p, Cells cells, const float* kxy, const 
   static LdsLimit limit;
   int rc = set_lds(kern, lds, limit);
   if (rc != DPC_OK) return rc;
-  DPC_LAUNCH("k_splat_hw", kern, dim3(((p->D + ZS - 1) / ZS) * p->B), dim3(ZS * 256), lds, st, *p, cells,
+  DPC_LAUNCH("k_splat_xl", kern, dim3(((p->D + ZS - 1) / ZS) * p->B), dim3(ZS * 256), lds, st, *p, cells,
              make_taps<RB>(kxy, pxy, false), Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
   return launch_ok();
 }

@@ -73,7 +73,7 @@ def lib():
             fn.restype = ctypes.c_int
             fn.argtypes = [pp] + [vp] * nptr
         L.dpc_project_loss_fwd.restype = ctypes.c_int
-        L.dpc_project_loss_fwd.argtypes = [pp] + [vp] * 8 + [ctypes.c_int] + [vp] * 11 + [ctypes.POINTER(ctypes.c_int), vp]
+        L.dpc_project_loss_fwd.argtypes = [pp] + [vp] * 8 + [ctypes.c_int] + [vp] * 12 + [ctypes.POINTER(ctypes.c_int), vp]
         L.dpc_project_loss_bwd.restype = ctypes.c_int
         L.dpc_project_loss_bwd.argtypes = [pp] + [vp] * 13 + [ctypes.c_int] + [vp] * 2 + [ctypes.c_int] + [vp] * 4
         L.dpc_splat_fwd.restype = ctypes.c_int

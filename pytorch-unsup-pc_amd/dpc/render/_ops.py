@@ -239,6 +239,7 @@ class ProjectLossFused(torch.autograd.Function):
         f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         grid_wh, proj, trans = f32e(B, geom.D, geom.H, geom.W), f32e(B, geom.H, geom.W, 1), f32e(B, geom.H, geom.W)
         sse, loss = f32e(B), torch.empty((), dtype=torch.float32, device=dev)
+        sse_tiles = f32e(B, (geom.H * geom.W + 255) // 256)   # per-tile partials of the unfused ray march (fixed-order sum)
         mask = torch.empty((B, geom.D, wpp), dtype=torch.int64, device=dev)
         winner = torch.empty((S,), dtype=torch.int32, device=dev)
         cells = _new_cells(P, dev)
@@ -254,7 +255,7 @@ class ProjectLossFused(torch.autograd.Function):
         with torch.cuda.device(dev):
             rc = L.dpc_project_loss_fwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
                                         N.ptr(gt32), K, None, N.ptr(cells), N.ptr(grid_wh), N.ptr(mask), N.ptr(proj),
-                                        N.ptr(trans), N.ptr(sse), N.ptr(loss), N.ptr(winner), N.ptr(ws), N.ptr(dsmall),
+                                        N.ptr(trans), N.ptr(sse), N.ptr(sse_tiles), N.ptr(loss), N.ptr(winner), N.ptr(ws), N.ptr(dsmall),
                                         ctypes.byref(fused), N.stream_ptr(dev))
         N.check(rc, "dpc_project_loss_fwd")
         ctx.geom, ctx.K, ctx.fused = geom, K, bool(fused.value)

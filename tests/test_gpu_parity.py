@@ -789,6 +789,14 @@ def test_config5_full_size(R, O):
     close(proj[sl], ref["proj"], TOL, "c5 proj vs oracle")
     close(gp.grad[sl], cp.grad, TOL, "c5 dpc vs oracle")
     close(gq.grad[sl], cq.grad, TOL, "c5 dq vs oracle")
+    # a second run: the K-candidate path (unfused ray march, per-tile partials added in order by the finalize launch) gives
+    # the same bits -- loss, winners and every gradient (this test materialises the clouds: no shared-set atomics)
+    first = [loss.detach().clone(), win.clone(), gp.grad.clone(), gq.grad.clone(), gs.grad.clone()]
+    gp.grad = gq.grad = gs.grad = None
+    loss2, _, win2 = R.pointcloud_project_loss(cfg, gp, gq, None, None, kern, scaling_factor=gs, gt=dev(gtS), num_candidates=K)
+    loss2.backward()
+    for name, a, b in zip(("loss", "winner", "dpc", "dq", "ds"), first, [loss2.detach(), win2, gp.grad, gq.grad, gs.grad]):
+        assert torch.equal(a, b), "c5: %s differs between two runs" % name
 
 
 def test_many_chunks_fallback_iteration(R, O):

@@ -3,16 +3,18 @@
 # VALU are.  Runs on the GPU box via gpurun; output gpurun_out/pmc/summary.txt
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/pmc; rm -rf $OUT; mkdir -p $OUT
-BENCH="python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-extras --no-graph"
+CONFIG=${1:-c2}
+OUT=gpurun_out/pmc_$CONFIG; rm -rf $OUT; mkdir -p $OUT
+BENCH="python3 bench.py --config $CONFIG --steps 30 --warmup 5 --no-cpu-baseline --no-extras --no-graph"
 i=0
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_INST_CYCLES_VMEM SQ_WAIT_ANY"; do
   i=$((i+1))
   rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- $BENCH > $OUT/p$i.log 2>&1; echo "pass $i ($grp) exit=$?"
 done
-python3 - <<'PY'
+python3 - $OUT <<'PY'
 import csv, glob, collections, re, os
-out = "gpurun_out/pmc"
+import sys
+out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):

@@ -10,6 +10,7 @@ import re
 import sys
 
 out = sys.argv[1]
+config = sys.argv[2] if len(sys.argv) > 2 else "c2"
 
 
 def short(name):
@@ -55,7 +56,7 @@ for k in ("calib_copy_dword", "calib_copy_dwordx4"):
 fetch, write = counter_avg("fetch", "FETCH_SIZE"), counter_avg("write", "WRITE_SIZE")
 # which calibration applies: column kernels and locate use dword-per-lane streams, slab kernels 16 B per lane
 width = {"k_zcol_fwd": "calib_copy_dword", "k_zcol_bwd": "calib_copy_dword", "k_zcol_fwdbwd": "calib_copy_dword", "k_locate": "calib_copy_dword",
-         "k_splat_hw": "calib_copy_dwordx4", "k_gather_hw": "calib_copy_dwordx4", "k_loss_finalize": "calib_copy_dword"}
+         "k_splat_hw": "calib_copy_dwordx4", "k_splat_xl": "calib_copy_dwordx4", "k_gather_hw": "calib_copy_dwordx4", "k_loss_finalize": "calib_copy_dword"}
 kern = {}
 for k in sorted(set(fetch) | set(write)):
     base = re.sub(r"<.*", "", k)
@@ -66,7 +67,7 @@ for k in sorted(set(fetch) | set(write)):
     wb = write.get(k, 0.0) * (c.get("write_bytes_per_count") or 0.0)
     kern[k] = dict(avg_us=stats.get(k, {}).get("avg_us"), fetch_counter=fetch.get(k), write_counter=write.get(k),
                    hbm_read_bytes=fb, hbm_write_bytes=wb, hbm_bytes_per_launch=fb + wb)
-json.dump(dict(calibration=calib, kernels=kern, kernel_stats=stats), open(os.path.join(out, "summary.json"), "w"), indent=1)
+json.dump(dict(config=config, calibration=calib, kernels=kern, kernel_stats=stats), open(os.path.join(out, "summary.json"), "w"), indent=1)
 for k, v in kern.items():
     print("%-28s avg %8s us   HBM read %8.2f MB  write %8.2f MB" % (k, "%.1f" % v["avg_us"] if v["avg_us"] else "?", v["hbm_read_bytes"] / 1e6, v["hbm_write_bytes"] / 1e6))
 print("calibration", json.dumps(calib))
