@@ -15,15 +15,19 @@ __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__
                                                        int S, int K, float inv_S, float* __restrict__ loss,
                                                        int* __restrict__ winner) {
   __shared__ float red[256 / DPC_WAVE];
+  // one thread per cloud adds its tiles (independent loads, tile order), then one thread per sample picks the winner
+  for (int cloud = threadIdx.x; cloud < S * K; cloud += blockDim.x) {
+    float v = 0.f;
+    for (int i = 0; i < ntile; ++i) v += sse_tiles[(size_t)cloud * ntile + i];
+    sse[cloud] = v;
+  }
+  __syncthreads();  // sse[] was written by this block: visible to its threads behind the barrier
   float acc = 0.f;
   for (int smp = threadIdx.x; smp < S; smp += blockDim.x) {
     float best = 0.f;
     int bk = 0;
     for (int k = 0; k < K; ++k) {
-      const size_t cloud = (size_t)smp * K + k;
-      float v = 0.f;
-      for (int i = 0; i < ntile; ++i) v += sse_tiles[cloud * ntile + i];
-      sse[cloud] = v;
+      const float v = sse[(size_t)smp * K + k];
       if (k == 0 || v < best) { best = v; bk = k; }  // first minimum wins, like torch.argmin
     }
     winner[smp] = bk;
