@@ -18,6 +18,7 @@ import torch
 
 from . import _native
 from ._ops import Drc, Geometry, ProjectFused, ProjectLossFused, SilhouetteLoss, Smooth, Splat, Transform
+from .predictions import chamfer_of_predictions, load_predictions, save_predictions  # noqa: F401
 
 __all__ = [
     "pointcloud_project_fast", "pointcloud_project", "pc_perspective_transform", "pointcloud2voxels3d_fast",
@@ -25,7 +26,7 @@ __all__ = [
     "drc_projection", "drc_event_probabilities", "drc_depth_projection", "drc_depth_grid", "pc_point_dropout",
     "quaternion_rotate", "quaternion_multiply", "quaternion_conjugate", "quaternion_normalise",
     "get_smooth_sigma", "get_dropout_prob", "ProjectionOutputs", "silhouette_loss", "pointcloud_project_loss",
-    "point_cloud_distance", "compute_distance", "chamfer_distances", "graphed_project_loss", "point_dropout_indices",
+    "point_cloud_distance", "compute_distance", "chamfer_distances", "graphed_project_loss", "point_dropout_indices", "save_predictions", "load_predictions", "chamfer_of_predictions",
 ]
 
 

@@ -146,3 +146,25 @@ def test_util_shims_expose_reference_names():
     assert callable(util.gauss_kernel.smoothing_kernel) and callable(util.quaternion.quaternion_rotate)
     np.testing.assert_allclose(util.drc.drc_depth_grid(__import__("oracle.dpc_oracle", fromlist=["Cfg"]).Cfg(), 4).numpy(),
                                [1.5, 1.75, 2.0, 2.25, 10.0])
+
+
+def test_prediction_files_are_the_reference_format(tmp_path):
+    """`<model>_pc.pkl` (dpc/run/predict_to.py:331-336 writes it, dpc/run/eval_chamfer_to.py:95-107 reads it): a file
+    written the reference's way loads here, a file written here is what the reference's reader expects."""
+    import pickle
+
+    import dpc.render as R
+
+    rs = np.random.RandomState(0)
+    pts, cam = rs.rand(5, 40, 3).astype(np.float32), rs.rand(5, 4).astype(np.float32)
+    ref_file = tmp_path / "ref_pc.pkl"
+    with open(ref_file, "wb") as handle:   # the writer of predict_to.py, verbatim in effect
+        pickle.dump({"points": pts, "camera_pose": cam}, handle, protocol=pickle.HIGHEST_PROTOCOL)
+    p, c, n = R.load_predictions(str(ref_file))
+    assert np.array_equal(p, pts) and np.array_equal(c, cam) and n is None
+    ours = tmp_path / "ours_pc.pkl"
+    R.save_predictions(str(ours), torch.from_numpy(pts), torch.from_numpy(cam), num_points=np.array([40, 30, 40, 10, 40]))
+    with open(ours, "rb") as handle:       # the reader of eval_chamfer_to.py
+        data = pickle.load(handle)
+    assert set(data) == {"points", "camera_pose", "num_points"} and isinstance(data["points"], np.ndarray)
+    assert np.array_equal(np.squeeze(data["points"]), pts) and np.array_equal(np.squeeze(data["num_points"]), [40, 30, 40, 10, 40])

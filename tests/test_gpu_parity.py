@@ -926,6 +926,25 @@ def test_chamfer_pair_golden(R):
     assert np.isclose(md.mean(), g["chamfer_pair"][0], rtol=1e-13)
 
 
+def test_chamfer_of_prediction_files(R, tmp_path):
+    """The evaluation's model loop (dpc/run/eval_chamfer_to.py:108-130) on a prediction file: per view the two directed mean
+    nearest distances, with the per-view point counts and the reference rotation of the unsupervised evaluation, against
+    brute-force numpy."""
+    rs = np.random.RandomState(3)
+    pts = rs.rand(3, 300, 3).astype(np.float32) - 0.5
+    gt = (rs.rand(500, 3) - 0.5).astype(np.float64)
+    nums = np.array([300, 120, 250])
+    quat = np.array([[0.9, 0.1, -0.3, 0.2]])
+    path = str(tmp_path / "m_pc.pkl")
+    R.save_predictions(path, pts, num_points=nums)
+    p, _, n = R.load_predictions(path)
+    got = R.chamfer_of_predictions(p, gt, reference_rotation=quat, num_points=n)
+    for i in range(3):
+        pr = R.quaternion_rotate(torch.from_numpy(p[i, :nums[i]]).unsqueeze(0), torch.from_numpy(quat)).squeeze(0).numpy()
+        d = np.sqrt(((pr[:, None, :].astype(np.float64) - gt[None]) ** 2).sum(-1))
+        assert abs(got[i, 0] - d.min(1).mean()) < 1e-6 and abs(got[i, 1] - d.min(0).mean()) < 1e-6
+
+
 def test_nearest_point_errors(R):
     with pytest.raises(IndexError):
         R.point_cloud_distance(torch.zeros(3, 3, device="cuda"), torch.zeros(0, 3, device="cuda"))
