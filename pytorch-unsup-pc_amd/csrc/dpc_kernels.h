@@ -320,6 +320,24 @@ constexpr float kFixScale = 17592186044416.0f;          // 2^44: splat weights a
 constexpr float kFixInv = 1.0f / 17592186044416.0f;
 constexpr unsigned long long kFixOne = 1ull << 44;
 
+// Conversions between fp32 and the 64-bit fixed point, written on the two 32-bit halves.  Left as `(unsigned long long)(w *
+// 2^44)` and `(float)(a >> 32) ...` the compiler expands generic 64-bit <-> float conversions (it widens the halves back to
+// i64 first): a dozen instructions each, in kernels that are bound by instruction issue.
+//   weight -> fixed point: trunc(w 2^44) = trunc(w 2^12) 2^32 + trunc((w 2^12 - trunc(w 2^12)) 2^32); every step exact
+__device__ inline unsigned long long to_fixed(float w) {
+  const float scaled = w * 4096.0f;                         // w 2^12, exact
+  const unsigned int hi = (unsigned int)scaled;             // v_cvt_u32_f32 truncates
+  const float rem = scaled - (float)hi;                     // exact: both are multiples of ulp(scaled), 0 <= rem < 1
+  const unsigned int lo = (unsigned int)(rem * 4294967296.0f);
+  return ((unsigned long long)hi << 32) | lo;
+}
+//   fixed point -> float: a < 2^56: hi < 2^24 converts exactly, lo rounds once, the fma rounds once more (<= 1 ulp overall)
+__device__ inline float from_fixed(unsigned long long a) {
+  unsigned int hi = (unsigned int)(a >> 32), lo = (unsigned int)a;
+  asm("" : "+v"(hi), "+v"(lo));                             // opaque: keep the halves 32-bit (two v_cvt_f32_u32)
+  return fmaf((float)hi, 0x1p-12f, (float)lo * kFixInv);
+}
+
 // In-place W-pass over NPL planes.  MASK: 0 none, 1 emit the clamp mask from the raw values (forward),
 // 2 multiply the outputs by the stored mask bits (backward).  mask32 points at this slab's first plane.
 template <class Geo, int GS, int NPL>

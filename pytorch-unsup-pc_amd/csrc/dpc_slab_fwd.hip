@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
           for (int e = 0; e < 2; ++e) {
             if (c.ix + e >= GS) continue;
             const float w = c.wz[k] * c.wy[j] * c.wx[e];
-            atomicAdd(&acc[(zz * GS + c.iy + j) * WPA + Geo::PAD + c.ix + e], (unsigned long long)(w * kFixScale));  // ds_add_u64
+            atomicAdd(&acc[(zz * GS + c.iy + j) * WPA + Geo::PAD + c.ix + e], to_fixed(w));  // ds_add_u64
           }
         }
       }
@@ -221,10 +221,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
     DPC_STAMP(2);
 
     const size_t wpp = (HW + 63) / 64;
-    // a < 2^56: hi < 2^24 converts exactly, lo rounds once, the fma rounds once more (<= 1 ulp overall)
-    auto to_float = [](unsigned long long a) {
-      return fmaf((float)(unsigned)(a >> 32), 0x1p-12f, (float)(unsigned)a * kFixInv);
-    };
+    auto to_float = [](unsigned long long a) { return from_fixed(a); };
     if (Tbuf == nullptr || RB == 0) {
       // stage-level splat (raw grid out) or no smoothing: plain conversion, lanes <-> consecutive x;
       // clamp mask straight from the integers (raw <= 1  <=>  acc <= 2^44)

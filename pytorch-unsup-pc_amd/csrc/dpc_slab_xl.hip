@@ -131,7 +131,7 @@ __global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells,
         for (int e = 0; e < 2; ++e) {
           if (c.ix + e >= kXG) continue;
           const float w = c.wz[k] * c.wy[j] * c.wx[e];
-          atomicAdd(&acc[(zz * PR + RB + c.iy + j) * kXG + c.ix + e], (unsigned long long)(w * kFixScale));  // ds_add_u64
+          atomicAdd(&acc[(zz * PR + RB + c.iy + j) * kXG + c.ix + e], to_fixed(w));  // ds_add_u64
         }
       }
     }
@@ -166,11 +166,9 @@ __global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells,
     mword = lane == j ? bits : mword;
   }
   if (lane < kXSeg) mask_out[lane] = mword;
-  // a < 2^56: hi < 2^24 converts exactly, lo rounds once, the fma rounds once more (<= 1 ulp overall)
   float v[WIN];
 #pragma unroll
-  for (int i = 0; i < WIN; ++i)
-    v[i] = fminf(fmaf((float)(unsigned)(a[i] >> 32), 0x1p-12f, (float)(unsigned)a[i] * kFixInv), 1.0f);
+  for (int i = 0; i < WIN; ++i) v[i] = fminf(from_fixed(a[i]), 1.0f);
   DPC_STAMP(3);
   // four rows at a time: H pass in registers, W pass across the lanes, then the quad transpose so that every lane stores
   // 16 contiguous bytes (lane 4q+e: row j+e, x = 4q .. 4q+3)
