@@ -91,11 +91,11 @@ __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_fwd(Dp
   double trans = 1.0;
   float y0 = 0.f;
   if (live) {
-    const float* col = Tbuf + (size_t)b * DD * HW + ray;
     float* out = smoothed + (size_t)b * DD * HW + ray;
     float c[DD];
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Tbuf + (size_t)b * DD * HW), 0, DD * HW * 4, 0x00020000);
 #pragma unroll
-    for (int z = 0; z < DD; ++z) c[z] = col[(size_t)z * HW];
+    for (int z = 0; z < DD; ++z) c[z] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src, ray * 4, z * HW * 4, 0));  // one lane offset, plane offsets in SGPRs
 #pragma unroll
     for (int z = 0; z < DD; ++z) {
       float v2 = 0.f;
@@ -144,13 +144,22 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
   float sq = 0.f, ds_acc = 0.f;
   float y[DD][RPL], g[RPL], gT[RPL];
   if (live) {
+    // Column loads and dT stores go through buffer descriptors of this cloud's two grids: ONE 32-bit lane offset (the ray)
+    // for all of them, the plane offsets z*HW*4 in SGPRs -- the flat form cost a 64-bit vector add per access (135 of the
+    // kernel's 1 640 issue-bound VALU instructions).
     const float* col = Tbuf + (size_t)b * DD * HW + ray;
     float c[DD][RPL];  // T column, then y (encoded), then dL/dv3: each value dies as the next is born
+    if constexpr (RPL == 1) {
+      const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Tbuf + (size_t)b * DD * HW), 0, DD * HW * 4, 0x00020000);
 #pragma unroll
-    for (int z = 0; z < DD; ++z) {
-      const vec v = *reinterpret_cast<const vec*>(col + (size_t)z * HW);
+      for (int z = 0; z < DD; ++z) c[z][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src, ray * 4, z * HW * 4, 0));
+    } else {
 #pragma unroll
-      for (int r = 0; r < RPL; ++r) c[z][r] = v[r];
+      for (int z = 0; z < DD; ++z) {
+        const vec v = *reinterpret_cast<const vec*>(col + (size_t)z * HW);
+#pragma unroll
+        for (int r = 0; r < RPL; ++r) c[z][r] = v[r];
+      }
     }
     if (DPC_ABL(16)) {  // diagnostic: loads only
       float sum = 0.f;
@@ -231,6 +240,7 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
 #pragma unroll
     for (int k = 0; k < 2 * RB + 1; ++k) wadj[k] = taps_adj.w[k] * rc.s;
     float* out = dT + (size_t)b * DD * HW + ray;
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(dT + (size_t)b * DD * HW, 0, DD * HW * 4, 0x00020000);
 #pragma unroll
     for (int z = 0; z < DD + RB; ++z) {
       if (z < DD) {
@@ -256,7 +266,10 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
           }
           acc[r] = a;
         }
-        if (!DPC_ABL(18) || acc[0] == 123.456f) *reinterpret_cast<vec*>(out + (size_t)zo * HW) = acc;
+        if (!DPC_ABL(18) || acc[0] == 123.456f) {
+          if constexpr (RPL == 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, (float)acc[0]), dst, ray * 4, zo * HW * 4, 0);
+          else *reinterpret_cast<vec*>(out + (size_t)zo * HW) = acc;
+        }
       }
       if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
@@ -374,10 +387,10 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
   float ds_acc = 0.f;
   if (ray < HW && !cloud_loses(la, b)) {
     const RayConst rc = ray_const(rh, s, b);
-    const float* col = Tin + (size_t)b * DD * HW + ray;
     float c[DD], d[DD];
+    const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Tin + (size_t)b * DD * HW), 0, DD * HW * 4, 0x00020000);
 #pragma unroll
-    for (int z = 0; z < DD; ++z) c[z] = col[(size_t)z * HW];
+    for (int z = 0; z < DD; ++z) c[z] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src, ray * 4, z * HW * 4, 0));  // one lane offset, plane offsets in SGPRs
     float Tf;
     if (trans_in != nullptr) {
       Tf = trans_in[(size_t)b * HW + ray];  // saved by the forward
@@ -397,7 +410,7 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
       Tf = (float)trans;
     }
     const float g = ray_grad(P, la, dproj, proj, b, ray);
-    float* out = dT + (size_t)b * DD * HW + ray;
+    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(dT + (size_t)b * DD * HW, 0, DD * HW * 4, 0x00020000);
     const float* extra = dgrid_extra ? dgrid_extra + (size_t)b * DD * HW + ray : nullptr;  // gradient arriving at grid_wh itself
     // streaming over z: forward taps -> d(v2) -> adjoint taps, RB voxels behind
 #pragma unroll
@@ -422,7 +435,7 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
           if (zz >= 0 && zz < DD) acc = fmaf(taps_adj.w[k], d[zz], acc);
         }
         if (extra != nullptr) acc += extra[(size_t)zo * HW];
-        out[(size_t)zo * HW] = acc;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, acc), dst, ray * 4, zo * HW * 4, 0);
       }
       // keep the unrolled per-voxel chains from being interleaved across voxels (it would spill the columns)
       if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
