@@ -37,7 +37,7 @@ def step():
 
 for _ in range(5):
     step()
-NB = 64 * B
+NB = max(64 * B, 4096)   # one 16-slot row per workgroup of the largest grid (c4: 1024 forward slabs)
 buf = torch.zeros(NB * 16, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 L.dpc_debug_set_stamps(ctypes.c_void_p(buf.data_ptr()))
