@@ -353,6 +353,41 @@ def test_chain_vs_oracle(R, O, B, N, G, k, sigma, with_t, with_f):
         close(gf.grad, cf.grad, TOL, "df")
 
 
+@pytest.mark.parametrize("B,sigma,Gz,with_tf", [(9, 0.3, -1, False), (8, 0.45, -1, True), (3, 0.75, -1, False), (10, 1.0, -1, True),
+                                                (8, 1.4, -1, False), (5, 0.64, 32, True), (16, 0.64, 128, False)])
+def test_x_in_lanes_kernel_every_radius_bucket(R, O, B, sigma, Gz, with_tf):
+    """The 64-wide forward slab kernel (k_splat_xl: W pass over DPP wave shifts) at every effective radius it is built for
+    (sigma 0.3 -> 1 ... 1.4 -> 6 voxels), with batch sizes that do and do not take the XCD-aware workgroup map (multiples of 8
+    or not), with translation / focal length, and with depths other than the width (vox_size_z): plain API and the fused
+    one-candidate loss against the oracle."""
+    G, N = 64, 1200
+    cfg = O.Cfg(vox_size=G, vox_size_z=Gz, pc_gauss_kernel_size=21)
+    pc, q, s, gt, t, f = O.synth_inputs(B, N, G, 9000 + B, with_tf, with_tf)
+    leaf = lambda x: None if x is None else x.clone().requires_grad_(True)
+    cp, cq, cs, ct, cf = leaf(pc), leaf(q), leaf(s), leaf(t), leaf(f)
+    ref = O.pointcloud_project_fast(cfg, cp, cq, ct, None, O.smoothing_kernel(cfg, sigma), scaling_factor=cs, focal_length=cf)
+    rloss = ((ref["proj"] - gt) ** 2).sum() / B
+    rloss.backward()
+    kern = R.smoothing_kernel(cfg, sigma)
+    for fused in (False, True):
+        gp, gq, gs, gt_, gf = dev(pc, True), dev(q, True), dev(s, True), dev(t, t is not None), dev(f, f is not None)
+        if fused:
+            loss, out, _ = R.pointcloud_project_loss(cfg, gp, gq, gt_, None, kern, scaling_factor=gs, focal_length=gf, gt=dev(gt))
+        else:
+            out = R.pointcloud_project_fast(cfg, gp, gq, gt_, None, kern, scaling_factor=gs, focal_length=gf)
+            loss = ((out["proj"] - dev(gt)) ** 2).sum() / B
+        loss.backward()
+        tag = "xl sigma %g B %d %s: " % (sigma, B, "fused" if fused else "plain")
+        close(loss, rloss, TOL, tag + "loss")
+        close(out["proj"], ref["proj"], TOL, tag + "proj")
+        close(gp.grad, cp.grad, TOL, tag + "dpc")
+        close(gq.grad, cq.grad, TOL, tag + "dq")
+        close(gs.grad, cs.grad, TOL, tag + "ds")
+        if with_tf:
+            close(gt_.grad, ct.grad, TOL, tag + "dt")
+            close(gf.grad, cf.grad, TOL, tag + "df")
+
+
 def test_long_kernel_falls_back_to_staged(R, O):
     """Effective radius > 15 voxels exceeds the fused kernels' register window; same answer via stage kernels."""
     cfg = O.Cfg(vox_size=32, pc_gauss_kernel_size=41)
