@@ -203,7 +203,9 @@ def full_step_main(args, rank, world, local):
 
     cfg = chair_unsupervised(pc_point_dropout=args.keep)
     torch.manual_seed(0)                      # same initial weights on every rank
-    step = TrainStep(cfg, device, device_dropout=True)
+    if args.captured and world > 1:
+        raise SystemExit("--captured covers the single-process step (the overlapped gradient exchange runs eagerly)")
+    step = TrainStep(cfg, device, device_dropout=True, capturable=args.captured)
     sync = None
     if world > 1:
         sync = OverlappedGradAllReduce(step.nets.parameters(), bucket_mb=32, overlap=not args.no_overlap)
@@ -212,6 +214,9 @@ def full_step_main(args, rank, world, local):
     gen = torch.Generator().manual_seed(1234 + rank)
     images = torch.rand(nimg, 3, 128, 128, generator=gen).to(device)
     masks = (torch.rand(nimg, 1, 128, 128, generator=gen) > 0.5).float().to(device)
+    trainer = step
+    if args.captured:
+        step = trainer.capture(images, masks)   # replay(images, masks): copies the batch into the graph's inputs, one launch
     for _ in range(args.warmup):
         step(images, masks)
     torch.cuda.synchronize(device)
@@ -248,9 +253,9 @@ def full_step_main(args, rank, world, local):
             "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] (c3): per rank 8 objects x 4 views (32 images 128x128x3), K=4 pose "
-                                   "candidates -> 128 clouds x %d of 8000 pts -> 64^3, 21 taps sigma_rel 3.0, eager launches"
-                                   % int(8000 * args.keep),
-                       "parameters": sum(p.numel() for p in step.nets.parameters()),
+                                   "candidates -> 128 clouds x %d of 8000 pts -> 64^3, 21 taps sigma_rel 3.0, %s"
+                                   % (int(8000 * args.keep), "whole step as one HIP graph" if args.captured else "eager launches"),
+                       "parameters": sum(p.numel() for p in trainer.nets.parameters()),
                        "gradient_exchange": None if sync is None else
                        {"backend": dist.get_backend(), "buckets": sync.num_buckets, "bytes": sync.nbytes,
                         "overlapped_with_backward": not args.no_overlap}},
@@ -277,6 +282,8 @@ def main():
                     help="BASELINE config (default c2 = the metric's); c3 = the full training step with the RCCL gradient exchange")
     ap.add_argument("--keep", type=float, default=1.0, help="c3: point keep-probability of the dropout (1.0 = all 8000 points)")
     ap.add_argument("--no-overlap", action="store_true", help="c3: all-reduce after the backward instead of inside it")
+    ap.add_argument("--captured", action="store_true",
+                    help="c3, one rank: the whole step (networks, renderer, loss, backward, Adam) replayed as ONE HIP graph")
     ap.add_argument("--api", choices=["fused", "plain"], default="fused",
                     help="fused: pointcloud_project_loss (renderer + loss in one autograd node, the default and the contract "
                          "line); plain: the reference's own call sequence, pointcloud_project_fast then the loss in torch")

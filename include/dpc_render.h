@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define DPC_ABI_VERSION 10
+#define DPC_ABI_VERSION 11
 #define DPC_MAX_TAPS 63 /* longest 1-D smoothing kernel accepted (pc_gauss_kernel_size) */
 
 enum {
@@ -177,6 +177,13 @@ int dpc_transform_fwd(const DpcParams* p, const float* pc, const float* q, const
 /* dout [B,N,3] -> dpc [B,N,3], dsmall (DPC_SMALL_COLS*B floats, block layout above: dq, dt, df; overwritten). */
 int dpc_transform_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                       const float* dout, float* dpc, float* dsmall, void* stream);
+
+/* pc_point_dropout's random choice (dpc/util/point_cloud_to.py:269-295: np.random.choice(N, n, replace=False) for every
+ * cloud) drawn on the device: out [B, n] int32 = for each of B clouds n DISTINCT indices in [0, N), a uniformly random
+ * n-subset, ascending.  seed: TWO int64 words in device memory (any values; equal seeds give equal draws) -- they are read
+ * by the kernel, so a captured graph whose seed words are refreshed by a captured RNG node draws anew at every replay.
+ * The result is what DpcParams.point_index expects.  No host work, no synchronisation. */
+int dpc_point_dropout_indices(int B, int N, int n, const int64_t* seed, int32_t* out, void* stream);
 
 /* pointcloud2voxels3d_fast (dpc/util/point_cloud_to.py:10-87): trilinear scatter of already-transformed
  * points tr [B,N,3] (z,y,x; fp32, or fp64 when tr_is_f64 -- the reference's direct callers pass fp64) into

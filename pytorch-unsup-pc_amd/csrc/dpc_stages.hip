@@ -263,6 +263,90 @@ __global__ __launch_bounds__(kThreads) void k_silhouette_loss(const float* __res
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// pc_point_dropout's random choice (dpc/util/point_cloud_to.py:269-295: np.random.choice(N, n, replace=False) per cloud),
+// drawn on the device: every point of a cloud gets a 32-bit key hashed from (seed, cloud, point); the cloud keeps the n
+// points with the smallest keys (ties: lower index first) = a uniformly random n-subset.  One workgroup per cloud: a
+// four-pass radix select finds the n-th smallest key (keys are recomputed, never stored), then an ordered compaction
+// writes the kept indices in ascending order.  seed[2] lives on the device (the caller draws it from torch's generator,
+// which is what makes the draw differ from replay to replay of a captured graph).
+// ------------------------------------------------------------------------------------------------------
+constexpr int kDropThreads = 1024;
+
+__device__ inline uint32_t dropout_key(uint64_t s0, uint64_t s1, int cloud, int i) {
+  uint64_t x = s0 ^ ((uint64_t)(uint32_t)cloud * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(uint32_t)i * 0xD1B54A32D192ED03ull);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;   // splitmix64 finaliser, twice, the second seed word in between
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  x += s1;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}
+
+__global__ __launch_bounds__(kDropThreads) void k_dropout_indices(int N, int n, const int64_t* __restrict__ seed,
+                                                                  int32_t* __restrict__ out) {
+  __shared__ int hist[256];
+  __shared__ uint32_t sel_prefix;
+  __shared__ int sel_remaining;
+  __shared__ int wave_less[kDropThreads / DPC_WAVE], wave_equal[kDropThreads / DPC_WAVE];
+  __shared__ int base_out, base_equal;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & (DPC_WAVE - 1), wave = tid / DPC_WAVE;
+  const uint64_t s0 = (uint64_t)seed[0], s1 = (uint64_t)seed[1];
+  if (tid == 0) { sel_prefix = 0u; sel_remaining = n; }
+  // radix select, most significant byte first: after pass p the top 8(p+1) bits of the n-th smallest key are known
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    const uint32_t prefix = sel_prefix;
+    const uint32_t high = pass == 0 ? 0u : (0xFFFFFFFFu << (shift + 8));
+    for (int i = tid; i < N; i += kDropThreads) {
+      const uint32_t k = dropout_key(s0, s1, b, i);
+      if ((k & high) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int remaining = sel_remaining, d = 0;
+      while (d < 255 && hist[d] < remaining) remaining -= hist[d++];
+      sel_prefix = prefix | ((uint32_t)d << shift);
+      sel_remaining = remaining;
+    }
+    __syncthreads();
+  }
+  const uint32_t T = sel_prefix;          // the n-th smallest key
+  const int take_equal = sel_remaining;   // how many of the keys == T are kept (>= 1 when n > 0)
+  if (tid == 0) { base_out = 0; base_equal = 0; }
+  __syncthreads();
+  int32_t* row = out + (size_t)b * n;
+  for (int i0 = 0; i0 < N; i0 += kDropThreads) {
+    const int i = i0 + tid;
+    const uint32_t k = i < N ? dropout_key(s0, s1, b, i) : 0xFFFFFFFFu;
+    const bool less = i < N && k < T, equal = i < N && k == T;
+    const uint64_t ml = __ballot(less), me = __ballot(equal);
+    if (lane == 0) { wave_less[wave] = __popcll(ml); wave_equal[wave] = __popcll(me); }
+    __syncthreads();
+    int less_before = 0, equal_before = 0, less_all = 0, equal_all = 0;
+    for (int w = 0; w < kDropThreads / DPC_WAVE; ++w) {
+      if (w < wave) { less_before += wave_less[w]; equal_before += wave_equal[w]; }
+      less_all += wave_less[w]; equal_all += wave_equal[w];
+    }
+    const uint64_t below = lane == 0 ? 0ull : (~0ull >> (DPC_WAVE - lane));
+    const int my_equal = base_equal + equal_before + __popcll(me & below);   // rank among the keys == T, in index order
+    const int kept_equal_before = min(base_equal + equal_before + __popcll(me & below), take_equal) - min(base_equal, take_equal);
+    const bool keep = less || (equal && my_equal < take_equal);
+    if (keep && n > 0) row[base_out + less_before + __popcll(ml & below) + kept_equal_before] = i;
+    __syncthreads();
+    if (tid == 0) {
+      const int eq_kept = min(base_equal + equal_all, take_equal) - min(base_equal, take_equal);
+      base_out += less_all + eq_kept;
+      base_equal += equal_all;
+    }
+    __syncthreads();
+  }
+}
+
 int blocks_for(size_t n) { return (int)std::min<size_t>((n + kThreads - 1) / kThreads, 256 * 8); }
 
 }  // namespace
@@ -305,6 +389,14 @@ int dpc_transform_bwd(const DpcParams* p, const float* pc, const float* q, const
     return DPC_ERR_LAUNCH;
   if (p->N == 0) return DPC_OK;
   hipLaunchKernelGGL(k_transform_bwd, dim3(p->B), dim3(kThreads), 0, (hipStream_t)stream, *p, pc, q, t, f, dout, dpc, dsmall);
+  return launch_ok();
+}
+
+int dpc_point_dropout_indices(int B, int N, int n, const int64_t* seed, int32_t* out, void* stream) {
+  if (B < 0 || N < 0 || n < 0 || n > N) return DPC_ERR_SHAPE;
+  if (B == 0 || n == 0) return DPC_OK;
+  if (!seed || !out) return DPC_ERR_NULL;
+  hipLaunchKernelGGL(k_dropout_indices, dim3(B), dim3(kDropThreads), 0, (hipStream_t)stream, N, n, seed, out);
   return launch_ok();
 }
 

@@ -39,7 +39,7 @@ def student_loss(poses, student, winner, num_candidates, weight):
 
 def device_point_dropout(points, keep_prob, generator=None):
     """pc_point_dropout (point_cloud_to.py:269-295) without the host: int(N*keep) distinct random points per cloud,
-    chosen by ranking device-side uniforms (dpc.render.point_dropout_indices).  Same distribution as the reference's
+    chosen on the device (dpc.render.point_dropout_indices).  Same distribution as the reference's
     np.random.choice(replace=False), different random stream.  Materialises the kept points; the
     training step below hands the INDICES to the renderer instead and keeps the point sets shared."""
     B, N = points.shape[0], points.shape[1]

@@ -425,13 +425,29 @@ def pc_point_dropout(points, rgb, keep_prob):
 
 def point_dropout_indices(num_clouds, num_points, keep_prob, device, generator=None):
     """Indices of pc_point_dropout (point_cloud_to.py:269-295) drawn on the device: for each of `num_clouds` clouds,
-    int(num_points * keep_prob) DISTINCT point indices, uniformly random (the ranks of num_points uniform numbers: the same
-    distribution as the reference's np.random.choice(replace=False), a different random stream).  int32 [num_clouds, n]
-    for the `point_index` argument of pointcloud_project_fast / pointcloud_project_loss; no host work, no upload, no sync,
-    safe inside HIP-graph capture."""
+    int(num_points * keep_prob) DISTINCT point indices, a uniformly random subset (the same distribution as the reference's
+    np.random.choice(replace=False), a different random stream), ascending.  int32 [num_clouds, n] for the `point_index`
+    argument of pointcloud_project_fast / pointcloud_project_loss.
+
+    Two 64-bit seed words come from torch's generator (`generator`, or the device's default one) and stay on the device;
+    the choice itself is one kernel of this library (dpc_point_dropout_indices: hashed keys + radix select).  No host work,
+    no upload, no sync, and safe inside HIP-graph capture: torch advances the generator at every replay, so every replay
+    draws anew.  (torch.topk / sort are NOT used here: replayed from a graph they returned out-of-range indices at
+    [128, 8000] on this ROCm build -- tests/test_gpu_parity.py::test_point_dropout_indices_in_a_replayed_graph.)"""
+    N = _native
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise RuntimeError("dpc.render: point_dropout_indices draws on a GPU, got device %s" % device)
     keep = int(num_points * keep_prob)
-    u = torch.rand(num_clouds, num_points, device=device, generator=generator)
-    return u.topk(keep, dim=1).indices.to(torch.int32)
+    if not 0 <= keep <= num_points:
+        raise ValueError("keep_prob %r leaves %d of %d points" % (keep_prob, keep, num_points))
+    seed = torch.randint(-2 ** 62, 2 ** 62, (2,), dtype=torch.int64, device=device, generator=generator)
+    out = torch.empty((num_clouds, keep), dtype=torch.int32, device=device)
+    with torch.cuda.device(device):
+        rc = N.lib().dpc_point_dropout_indices(int(num_clouds), int(num_points), keep, N.ptr(seed), N.ptr(out),
+                                               N.stream_ptr(device))
+    N.check(rc, "dpc_point_dropout_indices")
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------

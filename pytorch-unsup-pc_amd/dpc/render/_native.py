@@ -14,10 +14,11 @@ _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__))
 # other implementation to fall back to either way
 LIB_PATH = os.environ.get("DPC_RENDER_LIB") or os.path.join(_CSRC, "libdpc_render.so")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 DPC_MAX_TAPS = 63
 DPC_SMALL_COLS = 12
 COL_DQ, COL_DS, COL_DT, COL_DF = 0, 4, 5, 8
+DPC_ERR_SHAPE = -2
 DPC_ERR_TAPS = -3
 DPC_ERR_LDS = -4
 
@@ -26,7 +27,7 @@ SYMBOLS = (
     "dpc_abi_version", "dpc_strerror", "dpc_mask_words_per_plane", "dpc_cells_bytes", "dpc_workspace_bytes", "dpc_locate",
     "dpc_project_fwd", "dpc_project_bwd", "dpc_project_loss_fwd", "dpc_project_loss_bwd", "dpc_transform_fwd", "dpc_transform_bwd",
     "dpc_splat_fwd", "dpc_splat_bwd", "dpc_smooth", "dpc_drc_fwd", "dpc_drc_bwd",
-    "dpc_silhouette_loss", "dpc_nearest_workspace_bytes", "dpc_point_cloud_distance", "dpc_profile_enable", "dpc_profile_disable", "dpc_profile_count", "dpc_profile_get", "dpc_profile_pair_overhead",
+    "dpc_silhouette_loss", "dpc_point_dropout_indices", "dpc_nearest_workspace_bytes", "dpc_point_cloud_distance", "dpc_profile_enable", "dpc_profile_disable", "dpc_profile_count", "dpc_profile_get", "dpc_profile_pair_overhead",
 )
 
 
@@ -96,6 +97,8 @@ def lib():
         L.dpc_point_cloud_distance.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp, vp]
         L.dpc_smooth.restype = ctypes.c_int
         L.dpc_smooth.argtypes = [pp, vp, vp, ctypes.c_int, vp, vp, vp, vp]
+        L.dpc_point_dropout_indices.restype = ctypes.c_int
+        L.dpc_point_dropout_indices.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]
         if L.dpc_abi_version() != ABI_VERSION:
             raise RuntimeError("dpc.render: libdpc_render.so ABI %d, expected %d -- rebuild it (make -C %s)"
                                % (L.dpc_abi_version(), ABI_VERSION, _CSRC))

@@ -737,6 +737,69 @@ def test_point_dropout_indices_properties(R):
     assert torch.equal(sub, pts.gather(1, ind.long().unsqueeze(-1).expand(-1, -1, 3)))
 
 
+def _dropout_keys_numpy(seed, clouds, N):
+    """Host restatement of the library's key function (csrc/dpc_stages.hip::dropout_key): uint32 [clouds, N]."""
+    M = (1 << 64) - 1
+    s0, s1 = int(seed[0]) & M, int(seed[1]) & M
+    c = (np.arange(clouds, dtype=np.uint64)[:, None] * np.uint64(0x9E3779B97F4A7C15))
+    i = (np.arange(N, dtype=np.uint64)[None, :] * np.uint64(0xD1B54A32D192ED03))
+    with np.errstate(over="ignore"):
+        x = np.uint64(s0) ^ c ^ i
+
+        def mix(x):
+            x = x ^ (x >> np.uint64(30)); x = x * np.uint64(0xBF58476D1CE4E5B9)
+            x = x ^ (x >> np.uint64(27)); x = x * np.uint64(0x94D049BB133111EB)
+            return x ^ (x >> np.uint64(31))
+        x = mix(mix(x) + np.uint64(s1))
+    return (x >> np.uint64(32)).astype(np.uint32)
+
+
+@pytest.mark.parametrize("clouds,N,n", [(5, 8000, 560), (3, 1000, 70), (2, 1024, 1024), (2, 1025, 1), (1, 37, 36),
+                                        (4, 20000, 19999), (2, 3000, 0), (3, 64, 64)])
+def test_point_dropout_kernel_is_the_n_smallest_keys(clouds, N, n):
+    """dpc_point_dropout_indices through the C ABI against a host restatement: the kept set is exactly the n points with
+    the smallest hashed keys (ties broken by index), written in ascending order."""
+    import ctypes
+
+    from dpc.render import _native as Nat
+
+    d = torch.device("cuda")
+    seed = torch.tensor([0x1234567890ABCDEF - (1 << 63), 987654321], dtype=torch.int64, device=d)
+    out = torch.full((clouds, n), -7, dtype=torch.int32, device=d)
+    rc = Nat.lib().dpc_point_dropout_indices(clouds, N, n, Nat.ptr(seed), Nat.ptr(out), Nat.stream_ptr(d))
+    assert rc == 0
+    torch.cuda.synchronize()
+    keys = _dropout_keys_numpy(seed.cpu().numpy(), clouds, N)
+    order = np.lexsort((np.broadcast_to(np.arange(N), keys.shape), keys), axis=1)   # by key, then by index
+    want = np.sort(order[:, :n], axis=1)
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert Nat.lib().dpc_point_dropout_indices(1, 10, 11, Nat.ptr(seed), Nat.ptr(out), Nat.stream_ptr(d)) == Nat.DPC_ERR_SHAPE
+
+
+def test_point_dropout_indices_in_a_replayed_graph(R):
+    """The draw at the size of BASELINE config 3 (128 clouds x 8000 points, keep 0.07) captured in a HIP graph: every replay
+    gives valid, distinct, ascending indices and a NEW draw.  (Round 2 found torch.topk returning float bit patterns as
+    indices from the second replay on at this size -- the cause of the captured training step's memory fault.)"""
+    d = torch.device("cuda")
+    side = torch.cuda.Stream(d)
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            R.point_dropout_indices(128, 8000, 0.07, d)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        idx = R.point_dropout_indices(128, 8000, 0.07, d)
+    seen = []
+    for _ in range(4):
+        g.replay()
+        torch.cuda.synchronize()
+        a = idx.cpu().numpy().astype(np.int64)
+        assert a.shape == (128, 560) and a.min() >= 0 and a.max() < 8000
+        assert (np.diff(a, axis=1) > 0).all(), "not ascending / not distinct"
+        seen.append(a)
+    assert all(not np.array_equal(seen[0], s) for s in seen[1:]) and not np.array_equal(seen[1], seen[2])
+
+
 def test_graphed_project_loss(R, O):
     """The graph-captured step for eager loops: same loss and gradients as the eager call, on the sample data and on new
     data of the same shapes, called repeatedly."""

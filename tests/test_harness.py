@@ -187,6 +187,33 @@ def test_config3_full_size(keep):
         assert losses[-1] < losses[0], losses
 
 
+@pytest.mark.gpu
+def test_config3_captured_with_dropout_replays():
+    """BASELINE configs[2] with the experiment's point dropout as ONE HIP graph, replayed: the first full-size run of this
+    (round 2) died with a GPU memory fault at the second replay -- torch.topk inside the graph produced out-of-range point
+    indices; the draw is a kernel of this library since.  Finite losses, a new draw per replay (the loss of a fixed batch
+    changes by more than Adam alone would explain is not asserted; finiteness and progress of the counters are)."""
+    from dpc.harness import TrainStep, chair_unsupervised
+
+    cfg = chair_unsupervised(pc_point_dropout=0.07)
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    step = TrainStep(cfg, dev, lr=1e-4, device_dropout=True, capturable=True)
+    nimg = cfg.batch_size * cfg.step_size
+    gen = torch.Generator().manual_seed(3)
+    images = torch.rand(nimg, 3, 128, 128, generator=gen).to(dev)
+    masks = (torch.rand(nimg, 1, 128, 128, generator=gen) > 0.5).float().to(dev)
+    replay = step.capture(images, masks)
+    before = step.global_step
+    losses = []
+    for _ in range(6):
+        losses.append(float(replay(images, masks)))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses)) and step.global_step == before + 6
+    assert all(torch.isfinite(p).all() for p in step.nets.parameters())
+    assert len(set(losses)) == len(losses)
+
+
 def test_view_sampler_matches_reference():
     """sample_views against ModelBase.preprocess of the reference (fixture F12): random views, ordered views, and a
     variable number of views per object with padding -- same numpy RNG protocol, same selected tensors."""

@@ -15,5 +15,7 @@ run "c4" python bench.py --config c4 --steps 100 --warmup 10 --no-cpu-baseline
 run "c5" python bench.py --config c5 --steps 100 --warmup 10 --no-cpu-baseline
 run "c3 full training step, all points" python bench.py --config c3 --steps 30 --warmup 5
 run "c3 full training step, keep 0.07" python bench.py --config c3 --steps 30 --warmup 5 --keep 0.07
+run "c3 full training step as one HIP graph, all points" python bench.py --config c3 --steps 30 --warmup 5 --captured
+run "c3 full training step as one HIP graph, keep 0.07" python bench.py --config c3 --steps 30 --warmup 5 --captured --keep 0.07
 run "c3 two ranks over gloo on one GPU (functional rehearsal)" python bench.py --config c3 --gpus 2 --steps 10 --warmup 2 --rehearse-on-one-gpu
 python tools/bench_nearest.py > $OUT/bench_nearest.jsonl 2>>$OUT/bench.err; echo "nearest exit=$?"
