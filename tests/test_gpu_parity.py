@@ -737,6 +737,58 @@ def test_point_dropout_indices_properties(R):
     assert torch.equal(sub, pts.gather(1, ind.long().unsqueeze(-1).expand(-1, -1, 3)))
 
 
+@pytest.mark.parametrize("case", ["fused K=1", "K=4 shared sets + point_index", "plain call + torch loss", "64-wide x-in-lanes"])
+def test_results_do_not_depend_on_what_fresh_buffers_hold(R, O, case, monkeypatch):
+    """Every output buffer, workspace and record store the host layer allocates is handed over UNINITIALISED.  Run each entry
+    point twice -- once with those allocations pre-filled with 0xFF bytes (NaN floats, huge indices and counters), once
+    pre-filled with zeros -- and demand bit-identical losses, silhouettes and gradients: nothing may read what it did not
+    write.  (A captured graph's private pool hands out memory nobody has touched; eager runs mostly recycle the previous
+    step's buffers, which hides such reads.)"""
+    import dpc.render._ops as ops
+
+    real_empty = torch.empty
+    fill = [0xFF]
+
+    def poisoned_empty(*a, **k):
+        t = real_empty(*a, **k)
+        if t.is_cuda and t.numel():
+            t.view(-1).view(torch.uint8).fill_(fill[0])
+        return t
+
+    monkeypatch.setattr(ops.torch, "empty", poisoned_empty)
+    G = 64 if case == "64-wide x-in-lanes" else 32
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=21 if G == 64 else 11)
+    kern = R.smoothing_kernel(cfg, 0.64 if G == 64 else 0.9)
+    if case == "K=4 shared sets + point_index":
+        S, reps, K, N = 2, 8, 4, 1500
+        pc = O.synth_inputs(S, N, G, 6100)[0]
+        _, q, s, _, _, _ = O.synth_inputs(S * reps, 4, G, 6200)
+        gt = O.synth_inputs(S * reps // K, 1, G, 6300)[3]
+        idx = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b))[:400] for b in range(S * reps)]).int().cuda()
+    else:
+        B, N, K, idx = 8, 3000, 1, None
+        pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 6400)
+
+    def run(byte):
+        fill[0] = byte
+        gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+        if case == "plain call + torch loss":
+            proj = R.pointcloud_project_fast(cfg, gp, gq, None, None, kern, scaling_factor=gs)["proj"]
+            loss = ((proj - dev(gt)) ** 2).sum() / proj.shape[0]
+        else:
+            loss, out, _ = R.pointcloud_project_loss(cfg, gp, gq, None, None, kern, scaling_factor=gs, gt=dev(gt),
+                                                     num_candidates=K, point_index=idx)
+            proj = out["proj"]
+        loss.backward()
+        torch.cuda.synchronize()
+        return [x.detach().clone() for x in (loss, proj, gp.grad, gq.grad, gs.grad)]
+
+    a, b = run(0xFF), run(0x00)
+    for name, x, y in zip(("loss", "proj", "dpc", "dq", "ds"), a, b):
+        assert torch.isfinite(x).all(), name
+        assert torch.equal(x, y), "%s depends on the contents of a freshly allocated buffer (%s)" % (name, case)
+
+
 def _dropout_keys_numpy(seed, clouds, N):
     """Host restatement of the library's key function (csrc/dpc_stages.hip::dropout_key): uint32 [clouds, N]."""
     M = (1 << 64) - 1
