@@ -354,8 +354,9 @@ __device__ inline float ray_grad(const DpcParams& P, const LossArgs& la, const f
   return 2.0f * la.inv_S * up * (proj[(size_t)b * HW + pix] - la.gt[(size_t)(b / la.K) * HW + pix]);
 }
 
-__device__ inline void zcol_bwd_epilogue(float ds_acc, float* ds_part, float* dsmall, unsigned int* cg_count, const Blk& bk) {
-  const int b = bk.y;
+// b: the cloud of this workgroup; the small gradients of clouds [zero_lo, zero_lo + zero_n) are zeroed by part 0
+__device__ inline void zcol_bwd_epilogue(float ds_acc, float* ds_part, float* dsmall, unsigned int* cg_count, const Blk& bk,
+                                         int b, int B, int zero_lo, int zero_n) {
   __shared__ float red[kColThreads / DPC_WAVE];
   const float w = wave_sum(ds_acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = w;
@@ -365,7 +366,9 @@ __device__ inline void zcol_bwd_epilogue(float ds_acc, float* ds_part, float* ds
     for (int i = 0; i < kColThreads / DPC_WAVE; ++i) tot += red[i];
     ds_part[(size_t)b * bk.nx + bk.x] = tot;
   }
-  if (bk.x == 0 && threadIdx.x < DPC_SMALL_COLS) dsmall[(size_t)threadIdx.x * bk.ny + b] = 0.f;  // [col][B]
+  if (bk.x == 0)
+    for (int i = threadIdx.x; i < DPC_SMALL_COLS * zero_n; i += kColThreads)
+      dsmall[(size_t)(i / zero_n) * B + zero_lo + i % zero_n] = 0.f;  // [col][B]
   if (bk.x == 0 && threadIdx.x == 0) cg_count[b] = 0u;  // k_gather_hw's arrival counter of this cloud
 }
 
@@ -382,8 +385,9 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
                                                           float* __restrict__ dsmall, unsigned int* __restrict__ cg_count,
                                                           const float* __restrict__ dgrid_extra, LossArgs la) {
   const int HW = P.H * P.W;
-  const Blk bk = block_coords(P.B);
-  const int b = bk.y, ray = bk.x * kColThreads + threadIdx.x;
+  const bool wo = winners_only(la);  // grid over samples: this workgroup works on the winning candidate of sample bk.y
+  const Blk bk = block_coords(wo ? P.B / la.K : P.B);
+  const int b = wo ? bk.y * la.K + la.winner[bk.y] : bk.y, ray = bk.x * kColThreads + threadIdx.x;
   float ds_acc = 0.f;
   if (ray < HW && !cloud_loses(la, b)) {
     const RayConst rc = ray_const(rh, s, b);
@@ -441,7 +445,7 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
       if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
   }
-  zcol_bwd_epilogue(ds_acc, ds_part, dsmall, cg_count, bk);
+  zcol_bwd_epilogue(ds_acc, ds_part, dsmall, cg_count, bk, b, P.B, wo ? bk.y * la.K : b, wo ? la.K : 1);
 }
 
 __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHost rh, const float* __restrict__ Tin,
@@ -453,8 +457,9 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHo
                                                               float* __restrict__ dsmall, unsigned int* __restrict__ cg_count,
                                                               const float* __restrict__ dgrid_extra, LossArgs la) {
   const int HW = P.H * P.W, D = P.D;
-  const Blk bk = block_coords(P.B);
-  const int b = bk.y, ray = bk.x * kColThreads + threadIdx.x;
+  const bool wo = winners_only(la);  // grid over samples: this workgroup works on the winning candidate of sample bk.y
+  const Blk bk = block_coords(wo ? P.B / la.K : P.B);
+  const int b = wo ? bk.y * la.K + la.winner[bk.y] : bk.y, ray = bk.x * kColThreads + threadIdx.x;
   float ds_acc = 0.f;
   if (ray < HW && !cloud_loses(la, b)) {
     const RayConst rc = ray_const(rh, s, b);
@@ -501,7 +506,7 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHo
       out[(size_t)z * HW] = acc;
     }
   }
-  zcol_bwd_epilogue(ds_acc, ds_part, dsmall, cg_count, bk);
+  zcol_bwd_epilogue(ds_acc, ds_part, dsmall, cg_count, bk, b, P.B, wo ? bk.y * la.K : b, wo ? la.K : 1);
 }
 
 }  // namespace
@@ -555,7 +560,7 @@ int launch_zcol_bwd(const DpcParams* p, const float* host_kern_z, const TapPlan&
                     unsigned int* cg_count, const float* dgrid_extra, const LossArgs& la, hipStream_t st) {
   int rc = DPC_OK;
   const RayHost rh = ray_host(p);
-  dim3 gcol(col_tiles(p) * p->B);
+  dim3 gcol(col_tiles(p) * (winners_only(la) ? p->B / la.K : p->B));
   bool done = false;
 #define DPC_ZBWD(RB)                                                                                              \
   {                                                                                                               \

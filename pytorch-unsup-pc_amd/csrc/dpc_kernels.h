@@ -103,12 +103,21 @@ struct Blk {
   int x, y;    // part index (chunk / slab / ray tile), cloud
   int nx, ny;  // parts per cloud, clouds
 };
-__device__ inline Blk block_coords(int clouds) {
+// `group` > 1 (the backward with K pose candidates per sample, K = group): the candidates of sample s go to the XCD group
+// s % 8 instead, so that the ONE winning cloud per sample that has work to do lands on every XCD equally often (winners
+// share their candidate index more often than not, and cloud % 8 would pile them up on a few XCDs).
+__device__ inline Blk block_coords(int clouds, int group = 1) {
   Blk k;
   k.ny = clouds;
   k.nx = (int)gridDim.x / clouds;
   const int L = blockIdx.x;
 #ifndef DPC_NO_XCD_MAP
+  if (group > 1 && clouds % (8 * group) == 0) {
+    const int q = L >> 3, j = q / k.nx;  // j: running index of this XCD group's clouds
+    k.y = ((L & 7) + 8 * (j / group)) * group + j % group;
+    k.x = q % k.nx;
+    return k;
+  }
   if ((clouds & 7) == 0) {
     const int q = L >> 3;
     k.y = (L & 7) + 8 * (q / k.nx);
@@ -692,6 +701,13 @@ constexpr int kBwdZs64 = DPC_BWD_ZS64;  // cell layers per backward slab at G = 
 // losing pose candidates of the fused min-of-K loss do no backward work
 __device__ inline bool cloud_loses(const LossArgs& la, int b) {
   return la.gt != nullptr && la.winner[b / la.K] != b % la.K;
+}
+
+// K > 1 pose candidates per sample: only the winning cloud of a sample has any backward work.  The backward grids are
+// then (parts per cloud) x (SAMPLES) and a workgroup looks its cloud up -- launching a (1024-thread, 157 KB LDS)
+// workgroup per losing cloud just to let it return kept the winners' workgroups waiting for a CU (c5: 26 -> 15 us).
+__host__ __device__ inline bool winners_only(const LossArgs& la) {
+  return la.gt != nullptr && la.winner != nullptr && la.K > 1;
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -626,7 +626,8 @@ def test_shared_point_sets(R, O, K, reps, sig, G):
         R.pointcloud_project_fast(cfg, dev(pc[:2]), dev(q[:3]), None, None, kern)
 
 
-@pytest.mark.parametrize("K,reps,G,sig", [(1, 4, 32, 1.1), (2, 4, 32, 0.64), (4, 8, 64, 0.64), (1, 1, 32, 1.1)])
+@pytest.mark.parametrize("K,reps,G,sig", [(1, 4, 32, 1.1), (2, 4, 32, 0.64), (4, 8, 64, 0.64), (1, 1, 32, 1.1),
+                                          (4, 4, 32, 0.9), (2, 2, 64, 0.64)])   # K == reps: one writer per point set
 def test_point_index_vs_oracle(R, O, K, reps, G, sig):
     """Per-replica point dropout inside the kernels (reference: tf_repeat_0 then pc_point_dropout,
     dpc/models/model_pc_to.py:254-258, 302-306): cloud b projects point_cloud[b // R][point_index[b]].  Against the ORACLE
@@ -679,7 +680,7 @@ def test_point_index_vs_oracle(R, O, K, reps, G, sig):
     close(o2["tr_pc"], ref2["tr_pc"], 2e-6, "point_index: tr_pc of the kept points")
 
 
-@pytest.mark.parametrize("K,reps", [(1, 4), (4, 8)])
+@pytest.mark.parametrize("K,reps", [(1, 4), (4, 8), (4, 4), (2, 2)])   # K == reps: one writer per point set (K = reps = 8: the c5 test)
 def test_shared_point_sets_vs_oracle(R, O, K, reps):
     """Shared point sets without dropout (point_cloud [B/R,N,3], B poses) against the ORACLE on the tf_repeat_0 copies
     (dpc/models/model_pc_to.py:47-56, 302-306): silhouettes, winners, loss, d(pc) summed over the replicas, d(q), d(s)."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Per-phase timeline of the slab kernels from a -DDPC_ABLATE build (tools/build_variant.sh abl -DDPC_ABLATE):
-   DPC_RENDER_LIB=scratch/abl/libdpc_render.so python tools/stamps.py [c2|c4]
+   DPC_RENDER_LIB=scratch/abl/libdpc_render.so python tools/stamps.py [c2|c4|c5]
 Stamps are 100 MHz s_memrealtime values written by thread 0 of every workgroup (diagnostic build only)."""
 import ctypes
 import os
@@ -22,6 +22,8 @@ B, N, G, SIG, K = bench.CONFIGS[cfgname]
 cfg = chair_unsupervised(vox_size=G, pc_gauss_kernel_size=21)
 kern = R.smoothing_kernel(cfg, SIG)
 pc, q, s, gt = [x.cuda().float() for x in bench.synthetic_inputs(B, N, G, 1234)]
+if K > 1:  # like bench.py: the K candidates of a sample share its point set, scale and mask
+    pc, s, gt = pc[:B // K].contiguous(), s[:B // K].repeat_interleave(K, dim=0).contiguous(), gt[:B // K].contiguous()
 pc.requires_grad_(True), q.requires_grad_(True), s.requires_grad_(True)
 L = _native.lib()
 L.dpc_debug_set_stamps.argtypes = [ctypes.c_void_p]
@@ -31,7 +33,7 @@ L.dpc_debug_set_ablate(int(os.environ.get('DPC_ABL_BITS', '0'), 0))
 
 def step():
     pc.grad = q.grad = s.grad = None
-    loss, _, _ = R.pointcloud_project_loss(cfg, pc, q, None, None, kern, scaling_factor=s, gt=gt)
+    loss, _, _ = R.pointcloud_project_loss(cfg, pc, q, None, None, kern, scaling_factor=s, gt=gt, num_candidates=K)
     loss.backward()
 
 
