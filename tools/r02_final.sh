@@ -19,3 +19,4 @@ run "c3 full training step as one HIP graph, all points" python bench.py --confi
 run "c3 full training step as one HIP graph, keep 0.07" python bench.py --config c3 --steps 30 --warmup 5 --captured --keep 0.07
 run "c3 two ranks over gloo on one GPU (functional rehearsal)" python bench.py --config c3 --gpus 2 --steps 10 --warmup 2 --rehearse-on-one-gpu
 python tools/bench_nearest.py > $OUT/bench_nearest.jsonl 2>>$OUT/bench.err; echo "nearest exit=$?"
+bash tools/profile_c3.sh > $OUT/profile_c3.log 2>&1; echo "c3 profile exit=$?"; cp gpurun_out/prof_c3/kernel_stats_per_step.txt $OUT/ 2>/dev/null
