@@ -277,6 +277,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP graph replay")
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split", type=int, default=1,
+                    help="the batch of a step as this many independent sub-batches, each its own HIP graph on its own stream, "
+                         "joined at the end of every step (steps stay sequential)")
+    ap.add_argument("--in-flight", type=int, default=1,
+                    help="experiment: this many INDEPENDENT batches in flight (each its own buffers, HIP graph and stream, "
+                         "replayed round-robin); the default 1 is the contract's sequence of dependent-looking steps")
     ap.add_argument("--no-extras", action="store_true", help="skip the median/best windows and the forward-only timing "
                     "(profiling runs: keeps every traced kernel inside the contract's fwd+bwd step)")
     ap.add_argument("--config", choices=sorted(CONFIGS) + ["c3"], default="c2",
@@ -392,8 +398,71 @@ def main():
 
         last = [static_loss if graph is not None else None]
 
+        # --in-flight n > 1: n - 1 more lanes, each with its own inputs, gradients, workspace pool, graph and stream
+        def new_lane():
+            """One more independent batch: its own inputs, gradients, buffers, HIP graph and stream."""
+            lpc, lq, ls = (x.detach().clone().requires_grad_(True) for x in (pc, q, s))
+            lgt, lst = gt.clone(), torch.cuda.Stream(device)
+
+            def lane_step():
+                lpc.grad = lq.grad = ls.grad = None
+                loss, _, _ = R.pointcloud_project_loss(cfg, lpc, lq, None, None, kern, scaling_factor=ls, gt=lgt, num_candidates=K_CAND)
+                loss.backward(gradient=one)
+                return loss
+            with torch.cuda.stream(lst):
+                for _ in range(3):
+                    lane_step()
+                lst.synchronize()
+                lg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(lg, stream=lst, capture_error_mode="thread_local"):
+                    lane_step()
+            return lg, lst
+
+        lanes = []
+        if args.in_flight > 1:
+            if graph is None or ns != 1 or args.api != "fused":
+                raise SystemExit("--in-flight is an experiment of the graph-replayed fused step")
+            lanes = [new_lane() for _ in range(1, args.in_flight)]
+
+        # --split n: the step's batch as n sub-batches of B/n clouds: n graphs on n streams, fork and join on `side`
+        parts = []
+        if args.split > 1:
+            if graph is None or ns != 1 or args.api != "fused" or K_CAND != 1 or B % args.split or args.in_flight > 1:
+                raise SystemExit("--split is an experiment of the graph-replayed fused one-candidate step")
+            nb = B // args.split
+            frac = torch.full((), 1.0 / args.split, device=device)
+            for j in range(args.split):
+                lpc, lq, ls = (x[j * nb:(j + 1) * nb].detach().clone().requires_grad_(True) for x in (pc, q, s))
+                lgt, lst = gt[j * nb:(j + 1) * nb].clone(), torch.cuda.Stream(device)
+
+                def part_step(lpc=lpc, lq=lq, ls=ls, lgt=lgt):
+                    lpc.grad = lq.grad = ls.grad = None
+                    loss, _, _ = R.pointcloud_project_loss(cfg, lpc, lq, None, None, kern, scaling_factor=ls, gt=lgt, num_candidates=1)
+                    loss.backward(gradient=frac)   # every part's loss is a mean over B/n clouds
+                    return loss
+                with torch.cuda.stream(lst):
+                    for _ in range(3):
+                        part_step()
+                    lst.synchronize()
+                    lg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(lg, stream=lst, capture_error_mode="thread_local"):
+                        part_step()
+                parts.append((lg, lst))
+
         def run_step(i):
-            if graph is not None:
+            if parts:
+                for lg, lst in parts:
+                    lst.wait_stream(side)      # fork: the step starts when the previous one has been joined
+                    with torch.cuda.stream(lst):
+                        lg.replay()
+                for lg, lst in parts:
+                    side.wait_stream(lst)      # join
+                return
+            if lanes and i % args.in_flight:
+                lg, lst = lanes[i % args.in_flight - 1]
+                with torch.cuda.stream(lst):
+                    lg.replay()
+            elif graph is not None:
                 graph.replay()
             else:
                 last[0] = step()
@@ -415,7 +484,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
         wall = time.perf_counter() - t0
-        dev_ms = ev0.elapsed_time(ev1)
+        dev_ms = ev0.elapsed_time(ev1) if not lanes else wall * 1e3   # several streams: the events of one do not bracket the others
 
         tt = torch.tensor([wall], device=device, dtype=torch.float64)
         if world > 1:
@@ -448,6 +517,24 @@ def main():
                 return 1e3 * a.elapsed_time(b_) / n
             wins = sorted(window_us(graph.replay, 20) for _ in range(15))
             extras["step_us"] = {"median": wins[len(wins) // 2], "best": wins[0], "windows": "15 x 20 replays"}
+            if args.api == "fused" and ns == 1 and not lanes and not parts:
+                # NOT the contract's number: two INDEPENDENT batches in flight (second graph, second stream, no join between
+                # steps) -- how much of the one-chain step is latency and kernel tails that a second chain fills
+                lg, lst = new_lane()
+                torch.cuda.synchronize(device)
+                n2 = 200
+                for phase in range(2):   # first pass warms up
+                    t2 = time.perf_counter()
+                    for i in range(n2):
+                        if i & 1:
+                            with torch.cuda.stream(lst):
+                                lg.replay()
+                        else:
+                            graph.replay()
+                    torch.cuda.synchronize(device)
+                    t2 = time.perf_counter() - t2
+                extras["two_batches_in_flight"] = {"point_clouds_per_sec": B * n2 / t2, "us_per_batch": 1e6 * t2 / n2,
+                                                   "note": "independent batches on two streams; not the value of this line"}
 
             def fwd_only():
                 with torch.no_grad():
@@ -491,7 +578,7 @@ def main():
                                   2 * G, 2 * G, "loss sum((proj-gt)^2)/B" if K_CAND == 1 else
                                   "min-of-%d pose-candidate loss" % K_CAND),
                    "clouds_per_gpu": B, "points": N_PTS, "grid": G, "taps": KSIZE, "sigma_rel": SIGMA_REL,
-                   "launch": "eager" if graph is None else "hip-graph replay", "streams": ns, "api": args.api,
+                   "launch": "eager" if graph is None else "hip-graph replay", "streams": ns, "batches_in_flight": args.in_flight, "split": args.split, "api": args.api,
                    "sharding": "clouds, no collective"},
         "roofline": roofline,
         "roofline_step": {"bound": "hbm", "achieved": step_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
