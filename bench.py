@@ -35,6 +35,12 @@ for p in (ROOT, os.path.join(ROOT, "pytorch-unsup-pc_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# HIP-graph replay without the runtime's pre-built AQL packets ("graph packet capture", on by default in ROCm 7): with it
+# every kernel boundary inside a replayed graph costs about 1 us more on MI355X (c2: 61.2 -> 57.2 us per step, the same
+# kernels).  A runtime setting read when HIP initialises, so it is set before torch is imported;
+# an explicit value in the environment wins (DEBUG_CLR_GRAPH_PACKET_CAPTURE=1 python bench.py ... measures the default).
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # = dpc.render.prefer_direct_graph_launch()
+
 import torch
 import torch.distributed as dist
 
@@ -578,7 +584,8 @@ def main():
                                   2 * G, 2 * G, "loss sum((proj-gt)^2)/B" if K_CAND == 1 else
                                   "min-of-%d pose-candidate loss" % K_CAND),
                    "clouds_per_gpu": B, "points": N_PTS, "grid": G, "taps": KSIZE, "sigma_rel": SIGMA_REL,
-                   "launch": "eager" if graph is None else "hip-graph replay", "streams": ns, "batches_in_flight": args.in_flight, "split": args.split, "api": args.api,
+                   "launch": "eager" if graph is None else "hip-graph replay", "streams": ns, "batches_in_flight": args.in_flight, "split": args.split,
+                   "hip_graph_packet_capture": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0", "api": args.api,
                    "sharding": "clouds, no collective"},
         "roofline": roofline,
         "roofline_step": {"bound": "hbm", "achieved": step_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
