@@ -95,3 +95,26 @@ def test_measured_traffic_reads_the_committed_profile():
     b = _bench()
     t = b.measured_traffic("k_splat_xl") or b.measured_traffic("k_splat_hw")
     assert t is None or 1e6 < t < 1e9
+
+
+def test_committed_headline_line_carries_the_contract_fields():
+    """The first line of profiles/r02_bench_lines.jsonl is `python bench.py --steps 20 --warmup 5` as the driver runs it:
+    every field of the bench contract, the roofline and CPU-baseline objects, and the launch settings that shape `value`."""
+    import json
+
+    with open(os.path.join(ROOT, "profiles", "r02_bench_lines.jsonl")) as fh:
+        rec = json.loads(fh.readline())["line"]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in rec, key
+    assert rec["steps"] == 20 and rec["warmup"] == 5 and rec["n_gpus"] == 1 and rec["vs_baseline"] is None
+    assert abs(rec["value"] - 32 * 1e3 / rec["ms_per_step"]) < 1e-6 * rec["value"]
+    roof = rec["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert roof["traffic"] and roof["traffic"] > 0.9 * roof["algorithmic_bytes_per_launch"]
+    cpu = rec["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "32 clouds" in cpu["sample"]
+    cfg = rec["config"]
+    assert "model" not in cfg and cfg["workload"].startswith("BASELINE configs[1]")
+    assert cfg["hip_graph_packet_capture"] is False and cfg["batches_in_flight"] == 1 and cfg["split"] == 1
+    assert rec["two_batches_in_flight"]["point_clouds_per_sec"] > rec["value"]   # reported beside, never as, the value
