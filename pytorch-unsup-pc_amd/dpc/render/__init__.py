@@ -433,8 +433,8 @@ def prefer_direct_graph_launch():
 
     if not torch.cuda.is_initialized():
         os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
-        return os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "0"
-    return False  # too late to change; whatever the process started with stays
+    # once HIP is up the runtime has read the variable: what the process started with stays
+    return os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
 
 
 def point_dropout_indices(num_clouds, num_points, keep_prob, device, generator=None):

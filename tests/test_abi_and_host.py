@@ -168,3 +168,14 @@ def test_prediction_files_are_the_reference_format(tmp_path):
         data = pickle.load(handle)
     assert set(data) == {"points", "camera_pose", "num_points"} and isinstance(data["points"], np.ndarray)
     assert np.array_equal(np.squeeze(data["points"]), pts) and np.array_equal(np.squeeze(data["num_points"]), [40, 30, 40, 10, 40])
+
+
+def test_prefer_direct_graph_launch_sets_the_runtime_flag(monkeypatch):
+    """dpc.render.prefer_direct_graph_launch(): sets DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 while HIP is not initialised (never in
+    this CPU test process), leaves an explicit value alone, and reports what is in force."""
+    import dpc.render as R
+
+    monkeypatch.delenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", raising=False)
+    assert R.prefer_direct_graph_launch() is True and os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "0"
+    monkeypatch.setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1")
+    assert R.prefer_direct_graph_launch() is False and os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "1"
