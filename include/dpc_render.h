@@ -152,8 +152,10 @@ int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const f
  * ray-march kernel holds each ray's column in registers, so with one candidate per sample (K = 1) it can also run the
  * DRC backward + adjoint D pass for dloss = 1.  Pass bwd_workspace (dpc_workspace_bytes) and bwd_dsmall
  * (DPC_SMALL_COLS*B floats): when the configuration allows it, *column_backward_done is set to 1, the workspace holds
- * dT and the ds partials and bwd_dsmall is zeroed; hand the same two buffers and the flag to dpc_project_loss_bwd,
- * which then launches the gather kernel only (it multiplies by *dloss).  Pass NULLs / 0 to keep the two halves apart. */
+ * dT and the ds partials and bwd_dsmall is zeroed; hand the workspace and the flag to dpc_project_loss_bwd, which then
+ * launches the gather kernel only (it multiplies by *dloss).  dpc_project_loss_bwd WRITES dq, ds (and dt, df when t, f
+ * are given) into its `dsmall` -- any DPC_SMALL_COLS*B floats, need not be bwd_dsmall; the workspace is left as it was, so
+ * the backward may be called again on the same forward.  Pass NULLs / 0 to keep the two halves apart. */
 int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
                          const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt,
                          int num_candidates, float* tr_pc, void* cells, float* grid_wh, uint64_t* mask, float* proj,

@@ -282,10 +282,10 @@ class ProjectLossFused(torch.autograd.Function):
         P = geom.params(B, ctx.npts, reps, cells if ctx.indexed else None, pc32.shape[1])  # see ProjectFused.backward
         dl = dloss.detach().to(torch.float32).reshape(())
         dpc = torch.zeros_like(pc32) if (reps > 1 or ctx.indexed) else torch.empty_like(pc32)  # clouds add into a shared gradient
-        if ctx.fused:
-            out_small = dsmall   # zeroed by the forward's column kernel; dq/dt/df are written (not accumulated) by the gather
-        else:
-            out_small = torch.empty((N.DPC_SMALL_COLS * B,), dtype=torch.float32, device=dev)
+        # a FRESH block for dq / ds / dt / df on every call: k_gather_hw writes (never accumulates) them, and a block kept
+        # across calls would alias the .grad tensors autograd took over from an earlier backward through this same forward
+        out_small = torch.empty((N.DPC_SMALL_COLS * B,), dtype=torch.float32, device=dev)
+        if not ctx.fused:
             ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
         kxy, kz = geom.kern_ptrs()
         with torch.cuda.device(dev):

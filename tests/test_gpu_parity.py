@@ -790,6 +790,36 @@ def test_results_do_not_depend_on_what_fresh_buffers_hold(R, O, case, monkeypatc
         assert torch.equal(x, y), "%s depends on the contents of a freshly allocated buffer (%s)" % (name, case)
 
 
+@pytest.mark.parametrize("K,shared", [(1, False), (4, False), (4, True)])
+def test_backward_twice_through_one_forward(R, O, K, shared):
+    """loss.backward(retain_graph=True) twice: the second pass over the saved buffers (record store, grid, workspace with
+    its arrival counters and sum-and-count words) gives the same gradients again -- .grad ends at exactly twice the single
+    pass -- also with a different upstream factor."""
+    S, N, G = 2, 1200, 32
+    reps = K if shared else 1
+    B = S * K
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    kern = R.smoothing_kernel(cfg, 0.9)
+    pc, q, s, _, _, _ = O.synth_inputs(B, N, G, 7100 + K)
+    gt = O.synth_inputs(S, 1, G, 7200)[3]
+    if shared:
+        pc = pc[:S]
+
+    def grads(passes):
+        gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+        loss, _, _ = R.pointcloud_project_loss(cfg, gp, gq, None, None, kern, scaling_factor=gs, gt=dev(gt), num_candidates=K)
+        for i, up in enumerate(passes):
+            (up * loss).backward(retain_graph=i + 1 < len(passes))
+        return gp.grad, gq.grad, gs.grad
+
+    once = grads([1.0])
+    twice = grads([1.0, 1.0])
+    mixed = grads([0.5, 1.5])
+    for name, a, b_, c in zip(("dpc", "dq", "ds"), once, twice, mixed):
+        assert torch.equal(2.0 * a, b_), name + ": the second backward through the same forward differs"
+        close(c, 2.0 * a, TOL, name + " with upstream factors 0.5 + 1.5")
+
+
 def _dropout_keys_numpy(seed, clouds, N):
     """Host restatement of the library's key function (csrc/dpc_stages.hip::dropout_key): uint32 [clouds, N]."""
     M = (1 << 64) - 1
