@@ -820,6 +820,43 @@ def test_backward_twice_through_one_forward(R, O, K, shared):
         close(c, 2.0 * a, TOL, name + " with upstream factors 0.5 + 1.5")
 
 
+def test_plain_call_backward_twice_and_two_forwards_alive(R, O):
+    """pointcloud_project_fast: backward twice through one forward (retain_graph), also through the lazily derived dict
+    entries, and two forwards of different inputs alive at the same time before either backward runs."""
+    B, N, G = 5, 1400, 32
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    kern = R.smoothing_kernel(cfg, 0.9)
+    pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 7300)
+    pc2, q2, s2, gt2, _, _ = O.synth_inputs(B, N, G, 7301)
+
+    def leaves(a, b_, c):
+        return dev(a, True), dev(b_, True), dev(c, True)
+
+    def loss_of(out, g):
+        return ((out["proj"] - dev(g)) ** 2).sum() / B + 0.1 * out["proj_depth"].sum() / B
+
+    a = leaves(pc, q, s)
+    loss_of(R.pointcloud_project_fast(cfg, a[0], a[1], None, None, kern, scaling_factor=a[2]), gt).backward()
+    b_ = leaves(pc, q, s)
+    l2 = loss_of(R.pointcloud_project_fast(cfg, b_[0], b_[1], None, None, kern, scaling_factor=b_[2]), gt)
+    l2.backward(retain_graph=True)
+    l2.backward()
+    for name, x, y in zip(("dpc", "dq", "ds"), a, b_):
+        assert torch.equal(2.0 * x.grad, y.grad), name
+    # two forwards in flight, backwards in the opposite order
+    c, d = leaves(pc, q, s), leaves(pc2, q2, s2)
+    lc = loss_of(R.pointcloud_project_fast(cfg, c[0], c[1], None, None, kern, scaling_factor=c[2]), gt)
+    ld = loss_of(R.pointcloud_project_fast(cfg, d[0], d[1], None, None, kern, scaling_factor=d[2]), gt2)
+    ld.backward()
+    lc.backward()
+    e = leaves(pc2, q2, s2)
+    loss_of(R.pointcloud_project_fast(cfg, e[0], e[1], None, None, kern, scaling_factor=e[2]), gt2).backward()
+    for name, x, y in zip(("dpc", "dq", "ds"), a, c):
+        assert torch.equal(x.grad, y.grad), name + " (first of two forwards alive)"
+    for name, x, y in zip(("dpc", "dq", "ds"), e, d):
+        assert torch.equal(x.grad, y.grad), name + " (second of two forwards alive)"
+
+
 def _dropout_keys_numpy(seed, clouds, N):
     """Host restatement of the library's key function (csrc/dpc_stages.hip::dropout_key): uint32 [clouds, N]."""
     M = (1 << 64) - 1
