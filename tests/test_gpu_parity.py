@@ -506,6 +506,24 @@ def test_fused_loss_does_not_hide_divergence(R, O):
     assert np.isnan(run(bad_s, gt))
     assert np.isnan(run(s, gt * 200.0))        # squared errors beyond the range of the fixed-point words
     assert run(s, gt) == clean                 # the words start from zero again
+    # a NaN pose: the reference DROPS the cloud's points (masked_select on comparisons that are all false), so its loss stays
+    # finite and only that cloud's gradients are NaN (oracle: d(pc), d(q) of the cloud); same here, the other clouds untouched
+    bad_q = q.clone()
+    bad_q[2, 1] = float("nan")
+    cp, cq, cs = (x.clone().requires_grad_(True) for x in (pc, bad_q, s))
+    ref = O.pointcloud_project_fast(cfg, cp, cq, None, None, O.smoothing_kernel(cfg, 1.0), scaling_factor=cs)
+    rloss = ((ref["proj"] - gt) ** 2).sum() / B
+    rloss.backward()
+    gp, gq, gs = dev(pc, True), dev(bad_q, True), dev(s, True)
+    loss, out, _ = R.pointcloud_project_loss(cfg, gp, gq, None, None, kern, scaling_factor=gs, gt=dev(gt), num_candidates=1)
+    loss.backward()
+    assert np.isfinite(float(rloss)) and bool(torch.isnan(cq.grad[2]).all())
+    close(loss, rloss, TOL, "NaN pose: loss")
+    close(out["proj"], ref["proj"], TOL, "NaN pose: proj")
+    assert not bool(torch.isfinite(gq.grad[2]).any()), "the gradient of a NaN pose must not look healthy"
+    keep = [0, 1, 3]
+    close(gq.grad[keep], cq.grad[keep], TOL, "NaN pose: dq of the other clouds")
+    close(gp.grad[keep], cp.grad[keep], TOL, "NaN pose: dpc of the other clouds")
 
 
 def test_silhouette_loss_candidates(R, O, golden):
