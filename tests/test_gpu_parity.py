@@ -875,6 +875,33 @@ def test_plain_call_backward_twice_and_two_forwards_alive(R, O):
         assert torch.equal(x.grad, y.grad), name + " (second of two forwards alive)"
 
 
+def test_strided_and_fp64_inputs_of_the_fused_call(R, O):
+    """The fused call on inputs that are not fp32-contiguous: points as a strided view of a wider tensor, poses as every
+    second row of a longer one, scales in fp64.  Same silhouettes and loss; gradients arrive in the inputs' own dtype and
+    shape and land in the right rows of the tensors the views were cut from."""
+    B, N, G = 6, 1100, 32
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    kern = R.smoothing_kernel(cfg, 0.9)
+    pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 7400)
+    a = dev(pc, True), dev(q, True), dev(s, True)
+    la, oa, _ = R.pointcloud_project_loss(cfg, a[0], a[1], None, None, kern, scaling_factor=a[2], gt=dev(gt), num_candidates=1)
+    la.backward()
+    wide = torch.zeros(B, N, 5, device="cuda")
+    wide[:, :, 1:4] = dev(pc)
+    wide.requires_grad_(True)
+    long_q = torch.zeros(2 * B, 4, device="cuda")
+    long_q[::2] = dev(q)
+    long_q.requires_grad_(True)
+    s64 = dev(s, True, torch.float64)
+    lb, ob, _ = R.pointcloud_project_loss(cfg, wide[:, :, 1:4], long_q[::2], None, None, kern, scaling_factor=s64, gt=dev(gt),
+                                          num_candidates=1)
+    lb.backward()
+    assert torch.equal(la, lb) and torch.equal(oa["proj"], ob["proj"])
+    assert torch.equal(wide.grad[:, :, 1:4], a[0].grad) and float(wide.grad[:, :, 0].abs().max()) == 0.0 and float(wide.grad[:, :, 4].abs().max()) == 0.0
+    assert torch.equal(long_q.grad[::2], a[1].grad) and float(long_q.grad[1::2].abs().max()) == 0.0
+    assert s64.grad.dtype == torch.float64 and torch.equal(s64.grad.float(), a[2].grad)
+
+
 def _dropout_keys_numpy(seed, clouds, N):
     """Host restatement of the library's key function (csrc/dpc_stages.hip::dropout_key): uint32 [clouds, N]."""
     M = (1 << 64) - 1
