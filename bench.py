@@ -149,9 +149,16 @@ def cpu_baseline():
                 continue
             torch.set_num_threads(nt)
             by_threads[nt] = rate(nb, 2 if nt > 1 else 1, True)
-        best_nt = max(by_threads, key=by_threads.get)
+        # the FULL workload (all 32 clouds in one call), best of 3, at the two fastest thread counts of the sweep (a batch
+        # of 32 clouds does not always prefer the count the 4-cloud sample preferred)
+        value, best_nt = 0.0, 1
+        ranked = sorted(by_threads, key=by_threads.get, reverse=True)
+        for nt in [n for n in ranked[:2] if by_threads[n] >= 0.75 * by_threads[ranked[0]]]:
+            torch.set_num_threads(nt)
+            v = rate(B, 3, True)
+            if v > value:
+                value, best_nt = v, nt
         torch.set_num_threads(best_nt)
-        value = rate(B, 3, True)        # the FULL workload (all 32 clouds in one call), best of 3, at that thread count
         literal = rate(nb, 2, False)
     finally:
         torch.set_num_threads(threads)
@@ -166,7 +173,7 @@ def cpu_baseline():
         pass
     return {"value": value, "unit": "point-clouds/sec", "cores": best_nt, "kind": "port",
             "sample": "the full workload (%d clouds in one call), fwd+bwd with Gaussian (reference CUDA-branch semantics), "
-                      "fp64, best of 3 at the fastest of the thread counts tried on %d clouds (`cores` = that thread count)"
+                      "fp64, best of 3 at the faster of the two best thread counts of a sweep on %d clouds (`cores` = that thread count)"
                       % (B, nb),
             "value_by_threads": {str(k): v for k, v in by_threads.items()}, "value_no_smoothing": literal,
             "value_1thread": single, "cpu_model": model, "host_cpus": os.cpu_count()}
