@@ -217,11 +217,11 @@ def full_step_main(args, rank, world, local):
 
     cfg = chair_unsupervised(pc_point_dropout=args.keep)
     torch.manual_seed(0)                      # same initial weights on every rank
-    if args.captured and world > 1:
-        raise SystemExit("--captured covers the single-process step (the overlapped gradient exchange runs eagerly)")
-    step = TrainStep(cfg, device, device_dropout=True, capturable=args.captured)
+    if args.captured_compute:
+        args.captured = True
+    step = TrainStep(cfg, device, device_dropout=True, capturable=args.captured and world == 1 and not args.captured_compute)
     sync = None
-    if world > 1:
+    if world > 1 or args.captured_compute:
         sync = OverlappedGradAllReduce(step.nets.parameters(), bucket_mb=32, overlap=not args.no_overlap)
         step.grad_sync, step.sync_samples = sync, (cfg.batch_size, cfg.batch_size * world)
     nimg = cfg.batch_size * cfg.step_size
@@ -229,8 +229,10 @@ def full_step_main(args, rank, world, local):
     images = torch.rand(nimg, 3, 128, 128, generator=gen).to(device)
     masks = (torch.rand(nimg, 1, 128, 128, generator=gen) > 0.5).float().to(device)
     trainer = step
-    if args.captured:
+    if args.captured and world == 1 and not args.captured_compute:
         step = trainer.capture(images, masks)   # replay(images, masks): copies the batch into the graph's inputs, one launch
+    elif args.captured:
+        step = trainer.capture_compute(images, masks)   # forward + backward as one graph; exchange and Adam eager
     for _ in range(args.warmup):
         step(images, masks)
     torch.cuda.synchronize(device)
@@ -268,11 +270,11 @@ def full_step_main(args, rank, world, local):
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] (c3): per rank 8 objects x 4 views (32 images 128x128x3), K=4 pose "
                                    "candidates -> 128 clouds x %d of 8000 pts -> 64^3, 21 taps sigma_rel 3.0, %s"
-                                   % (int(8000 * args.keep), "whole step as one HIP graph" if args.captured else "eager launches"),
+                                   % (int(8000 * args.keep), ("whole step as one HIP graph" if world == 1 else "forward + backward as one HIP graph, exchange + Adam eager") if args.captured else "eager launches"),
                        "parameters": sum(p.numel() for p in trainer.nets.parameters()),
                        "gradient_exchange": None if sync is None else
-                       {"backend": dist.get_backend(), "buckets": sync.num_buckets, "bytes": sync.nbytes,
-                        "overlapped_with_backward": not args.no_overlap}},
+                       {"backend": dist.get_backend() if dist.is_initialized() else "none (one rank)", "buckets": sync.num_buckets, "bytes": sync.nbytes,
+                        "overlapped_with_backward": not args.no_overlap and not args.captured}},
             "train_steps_per_sec": world * args.steps / wall,
             "ms_per_step_by_rank": [1e3 * float(t[1]) / args.steps for t in per_rank],
             "allreduce_alone_ms": None if comm is None else 1e3 * comm,
@@ -302,6 +304,9 @@ def main():
                     help="BASELINE config (default c2 = the metric's); c3 = the full training step with the RCCL gradient exchange")
     ap.add_argument("--keep", type=float, default=1.0, help="c3: point keep-probability of the dropout (1.0 = all 8000 points)")
     ap.add_argument("--no-overlap", action="store_true", help="c3: all-reduce after the backward instead of inside it")
+    ap.add_argument("--captured-compute", action="store_true",
+                    help="c3: forward + backward as one HIP graph accumulating into the gradient buckets, exchange + Adam eager "
+                         "(what --captured does on several ranks), also on one rank")
     ap.add_argument("--captured", action="store_true",
                     help="c3, one rank: the whole step (networks, renderer, loss, backward, Adam) replayed as ONE HIP graph")
     ap.add_argument("--api", choices=["fused", "plain"], default="fused",

@@ -127,6 +127,47 @@ class TrainStep:
         self.global_step += 1
         return total.detach()
 
+    def capture_compute(self, images, masks, warmup=2):
+        """The multi-rank variant of capture(): forward, loss and backward as ONE HIP graph whose backward accumulates
+        straight into the flat buckets of `grad_sync` (every .grad is a view into them); the gradient exchange and Adam run
+        eagerly after each replay (OverlappedGradAllReduce.reduce_now -- collectives are not captured).  The eager step
+        hides the exchange under a launch-bound 4 ms backward; this one has a 2 ms step and exposes the exchange.
+        `warmup` eager steps run first: the first one fixes which parameters take part in the exchange.
+        Returns replay(images, masks) -> loss tensor."""
+        sync = self.grad_sync
+        if sync is None:
+            raise RuntimeError("capture_compute() is the step with a gradient exchange (set grad_sync); use capture() without")
+        if self.cfg.pc_point_dropout != 1 and not self.device_dropout:
+            raise RuntimeError("the reference's host-RNG point dropout uploads indices every step: not capturable; "
+                               "use device_dropout=True")
+        static_images, static_masks = images.clone(), masks.clone()
+        side = torch.cuda.Stream(self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self(static_images, static_masks)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        for p in sync.params:                 # what finish() left: views into the buckets
+            p.grad = sync.views[id(p)]
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for flat in sync.flat:
+                flat.zero_()
+            total, _ = self.loss(static_images, static_masks)
+            total.backward()                  # the hooks are disarmed: gradients simply land in the buckets
+        self._graph, static_loss = graph, total.detach()
+
+        def replay(new_images, new_masks):
+            static_images.copy_(new_images)
+            static_masks.copy_(new_masks)
+            graph.replay()
+            sync.reduce_now(*self.sync_samples)
+            self.optimizer.step()
+            self.global_step += 1
+            return static_loss
+
+        return replay
+
     def capture(self, images, masks, warmup=3):
         """Capture forward + loss + backward + Adam into one HIP graph (the standard whole-step recipe of
         torch.cuda.graphs: warm up on a side stream, capture with gradients set to None, replay on static inputs).

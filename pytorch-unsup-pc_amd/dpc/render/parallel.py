@@ -230,6 +230,32 @@ class OverlappedGradAllReduce:
             self._events[-1][1].synchronize()
         return self._host_exposed + 1e-3 * sum(a.elapsed_time(b) for a, b in self._events)
 
+    def reduce_now(self, local_samples, total_samples):
+        """The exchange for gradients that are ALREADY complete in the buckets (a backward that ran without the hooks, e.g.
+        replayed from a HIP graph, TrainStep.capture_compute): scale every bucket to this rank's share of the global mean
+        loss, all-reduce them all, wait.  Nothing overlaps with the backward here; the buckets still go out back to back."""
+        scale = float(local_samples) / float(total_samples)
+        on_gpu = self.flat[0].is_cuda
+        if on_gpu:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        else:
+            t0 = time.perf_counter()
+        works = []
+        for flat in self.flat:
+            if scale != 1.0:
+                flat.mul_(scale)
+            if self._active():
+                works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        if on_gpu:
+            ev[1].record()
+            self._events.append(ev)
+        else:
+            self._host_exposed += time.perf_counter() - t0
+        self.steps += 1
+
     def exchange_only(self):
         """The collectives alone on the current bucket contents (timing aid)."""
         if not self._active():

@@ -149,6 +149,36 @@ def test_captured_step_matches_eager(f10, keep):
 
 
 @pytest.mark.gpu
+def test_captured_compute_with_gradient_buckets_matches_eager(f10):
+    """TrainStep.capture_compute (the multi-rank form: forward + backward as one HIP graph accumulating into the exchange's
+    flat buckets, exchange + Adam eager) on one process -- the collectives are no-ops, everything else is what a rank runs:
+    same losses and parameters as the eager step with the same buckets after six optimiser steps."""
+    from dpc.harness import TrainStep
+    from dpc.render.parallel import OverlappedGradAllReduce
+
+    cfg, g, state, _ = f10
+    dev = torch.device("cuda")
+    images, masks = torch.from_numpy(g["images"]).to(dev), torch.from_numpy(g["masks"]).to(dev)
+
+    def make():
+        step = TrainStep(cfg, dev, lr=1e-3, device_dropout=True)
+        step.load_reference_state(state)
+        step.grad_sync, step.sync_samples = OverlappedGradAllReduce(step.nets.parameters(), bucket_mb=1), (1, 1)
+        return step
+
+    eager, captured = make(), make()
+    replay = captured.capture_compute(images, masks, warmup=2)
+    for _ in range(2):
+        eager(images, masks)
+    le = [float(eager(images, masks)) for _ in range(4)]
+    lc = [float(replay(images, masks)) for _ in range(4)]
+    assert captured.global_step == eager.global_step == 6
+    assert np.allclose(le, lc, rtol=1e-4), (le, lc)
+    for (name, p), q in zip(eager.nets.named_parameters(), captured.nets.parameters()):
+        assert float((p.detach() - q.detach()).abs().max()) < 1e-4, name
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("keep", [1.0, 0.07])
 def test_config3_full_size(keep):
     """BASELINE configs[2] at full size inside the test suite: the chair_unsupervised step (61 M parameters, 8 objects x 4
