@@ -14,6 +14,8 @@
  *     synchronises the stream (so calls can be captured into a hipGraph);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream);
  *   - return value: DPC_OK (0) or a negative DPC_ERR_* code; dpc_strerror() names it;
+ *   - B == 0 (no clouds: an empty shard) is valid everywhere: nothing is launched, array pointers may be NULL, and
+ *     dpc_project_loss_fwd writes loss = 0;
  *   - re-entrant, no global state; arithmetic type fp32 (the ray-march transmittance product runs in fp64
  *     registers); tensors are dense row-major with the shapes stated per argument;
  *   - optional inputs (t, f, s) and optional outputs are NULL when absent.

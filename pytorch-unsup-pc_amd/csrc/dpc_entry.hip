@@ -40,8 +40,8 @@ int dpc_locate(const DpcParams* p, const float* pc, const float* q, const float*
 int dpc_splat_fwd(const DpcParams* p, const void* tr, int tr_is_f64, void* cells, float* vox, void* stream) {
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
-  if (!vox || (p->N > 0 && p->B > 0 && (!tr || !cells))) return DPC_ERR_NULL;
   if (p->B == 0) return DPC_OK;
+  if (!vox || (p->N > 0 && (!tr || !cells))) return DPC_ERR_NULL;
   hipStream_t st = (hipStream_t)stream;
   if ((rc = launch_locate(p, tr_is_f64 ? 2 : 1, tr, nullptr, nullptr, nullptr, nullptr, cells, st)) != DPC_OK) return rc;
   const TapPlan none{0, 0, 0};
@@ -67,10 +67,10 @@ int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const 
                      void* bwd_workspace, float* bwd_dsmall, hipStream_t st) {
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
+  if (p->B == 0) return DPC_OK;  // no clouds (an empty shard): every array is empty, its pointer may be NULL
   if (!q || !grid_wh || !mask || !proj) return DPC_ERR_NULL;
-  if (p->N > 0 && p->B > 0 && (!pc || !cells)) return DPC_ERR_NULL;
+  if (p->N > 0 && (!pc || !cells)) return DPC_ERR_NULL;
   if ((p->taps_xy > 0 && !host_kern_xy) || (p->taps_z > 0 && !host_kern_z)) return DPC_ERR_NULL;
-  if (p->B == 0) return DPC_OK;
   const TapPlan pxy = plan_taps(host_kern_xy, p->taps_xy), pz = plan_taps(host_kern_z, p->taps_z);
   if (pxy.bucket < 0) return DPC_ERR_TAPS;  // in-LDS passes need a radius bucket; caller composes the stage ops
   float* Tbuf = grid_wh;
@@ -100,11 +100,11 @@ int project_bwd_impl(const DpcParams* p, const float* pc, const float* q, const 
   const bool column_done = la.scale_in_gather != 0;  // dT, ds partials and zeroed dsmall come from the forward
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
+  if (p->B == 0) return DPC_OK;  // no clouds: nothing to write
   if (!q || !grid_wh || !mask || !dsmall || !workspace) return DPC_ERR_NULL;
   if (!column_done && (la.gt == nullptr ? !dproj : (!proj || !la.winner))) return DPC_ERR_NULL;
-  if (p->N > 0 && p->B > 0 && (!pc || !cells || !dpc)) return DPC_ERR_NULL;
+  if (p->N > 0 && (!pc || !cells || !dpc)) return DPC_ERR_NULL;
   if ((p->taps_xy > 0 && !host_kern_xy) || (p->taps_z > 0 && !host_kern_z)) return DPC_ERR_NULL;
-  if (p->B == 0) return DPC_OK;
   const TapPlan pxy = plan_taps(host_kern_xy, p->taps_xy), pz = plan_taps(host_kern_z, p->taps_z);
   if (pxy.bucket < 0) return DPC_ERR_TAPS;
   const Workspace w = workspace_view(p, workspace);
@@ -133,7 +133,7 @@ int dpc_project_bwd(const DpcParams* p, const float* pc, const float* q, const f
                     const float* s, const float* host_kern_xy, const float* host_kern_z, const void* cells,
                     const float* grid_wh, const uint64_t* mask, const float* trans, const float* dproj,
                     const float* dgrid_wh, float* dpc, float* dsmall, void* workspace, void* stream) {
-  if (!dproj) return DPC_ERR_NULL;
+  if (!dproj && !(p && p->B == 0)) return DPC_ERR_NULL;
   return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, grid_wh, mask, dproj, nullptr, trans,
                           kNoLoss, dpc, dsmall, workspace, dgrid_wh, (hipStream_t)stream);
 }
@@ -143,8 +143,11 @@ int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, co
                          int num_candidates, float* tr_pc, void* cells, float* grid_wh, uint64_t* mask, float* proj,
                          float* trans, float* sse, float* sse_tiles, float* loss, int32_t* winner, void* bwd_workspace,
                          float* bwd_dsmall, int* column_backward_done, void* stream) {
-  if (!p || !gt || !sse || !loss || !winner) return DPC_ERR_NULL;
+  if (!p || !loss) return DPC_ERR_NULL;
   if (num_candidates < 1 || p->B % num_candidates != 0) return DPC_ERR_SHAPE;
+  if (p->B == 0)   // no clouds (an empty shard): the loss of nothing is 0
+    return hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream) == hipSuccess ? DPC_OK : DPC_ERR_LAUNCH;
+  if (!gt || !sse || !winner) return DPC_ERR_NULL;
   const int S = p->B / num_candidates;
   // one candidate per sample AND a backward workspace: the fused ray march sums the loss itself (64-bit fixed point)
   const TapPlan pz = plan_taps(host_kern_z, p->taps_z);
@@ -166,8 +169,10 @@ int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, co
                          const float* grid_wh, const uint64_t* mask, const float* proj, const float* trans,
                          const float* gt, int num_candidates, const int32_t* winner, const float* dloss,
                          int column_backward_done, float* dpc, float* dsmall, void* workspace, void* stream) {
-  if (!p || !gt || !winner || !proj) return DPC_ERR_NULL;
+  if (!p) return DPC_ERR_NULL;
   if (num_candidates < 1 || p->B % num_candidates != 0) return DPC_ERR_SHAPE;
+  if (p->B == 0) return DPC_OK;  // no clouds: nothing to write
+  if (!gt || !winner || !proj) return DPC_ERR_NULL;
   const int S = p->B / num_candidates;
   const LossArgs la{gt, nullptr, winner, dloss, num_candidates, S > 0 ? 1.0f / (float)S : 0.f, nullptr, nullptr,
                     column_backward_done ? 1 : 0, nullptr};

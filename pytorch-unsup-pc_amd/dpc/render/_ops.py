@@ -85,6 +85,11 @@ def _like_input(grad, meta):
     return None if grad is None or meta is None else grad.to(meta[0]).reshape(meta[1])
 
 
+def _zero_grads(metas, dev):
+    """Backward of an empty batch (no clouds on this rank): zeros in every input's own dtype and shape."""
+    return tuple(None if m is None else torch.zeros(m[1], dtype=m[0], device=dev) for m in metas)
+
+
 def _new_cells(P, dev):
     return torch.empty((max(N.lib().dpc_cells_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
 
@@ -231,9 +236,18 @@ class ProjectLossFused(torch.autograd.Function):
         if K < 1 or B % K:
             raise ValueError("%d clouds is not a multiple of %d pose candidates" % (B, K))
         S = B // K
-        if gt32.shape[0] != S or gt32[0].numel() != geom.H * geom.W:
+        if gt32.shape[0] != S or gt32.numel() != S * geom.H * geom.W:
             raise ValueError("gt must be [%d,%d,%d,1] (masks pooled to the silhouette size), got %s"
                              % (S, geom.H, geom.W, tuple(gt32.shape)))
+        if B == 0:   # an empty shard (more ranks than samples): nothing to launch, loss 0, zero gradients
+            ctx.empty, ctx.dev = True, dev
+            ctx.inputs = tuple(_meta(x) for x in (pc, q, t, f, s))
+            ctx.set_materialize_grads(False)
+            proj = torch.zeros((0, geom.H, geom.W, 1), dtype=torch.float32, device=dev)
+            winner = torch.zeros((0,), dtype=torch.int32, device=dev)
+            ctx.mark_non_differentiable(proj, winner)
+            return torch.zeros((), dtype=torch.float32, device=dev), proj, winner
+        ctx.empty = False
         P = geom.params(B, Npts, reps, idx, pc32.shape[1])
         wpp = L.dpc_mask_words_per_plane(ctypes.byref(P))
         f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
@@ -274,6 +288,8 @@ class ProjectLossFused(torch.autograd.Function):
     def backward(ctx, dloss, _dproj, _dwinner):
         if dloss is None:
             return (None,) * 10
+        if ctx.empty:
+            return _zero_grads(ctx.inputs, ctx.dev) + (None,) * 5
         pc32, q32, t32, f32, s32, gt32, grid_wh, mask, cells, proj, trans, winner, ws, dsmall = ctx.saved_tensors
         has_t, has_f, has_s = ctx.has
         t32, f32, s32 = (t32 if has_t else None), (f32 if has_f else None), (s32 if has_s else None)

@@ -1090,6 +1090,43 @@ def test_empty_clouds_through_fused_path(R, O):
     assert out["proj"].shape == (2, 32, 32, 1) and abs(out["proj"].max().item() - empty) < 1e-7
     out["proj"].sum().backward()
     assert pc.grad.shape == (2, 0, 3) and q.grad.abs().max().item() == 0.0 and s.grad.abs().max().item() == 0.0
+    # no clouds at all (an empty shard)
+    pc0 = torch.zeros(0, 40, 3, device="cuda", requires_grad=True)
+    q0 = torch.ones(0, 4, device="cuda", requires_grad=True)
+    out0 = R.pointcloud_project_fast(cfg, pc0, q0, None, None, R.smoothing_kernel(cfg, 1.0))
+    assert out0["proj"].shape == (0, 32, 32, 1)
+    out0["proj"].sum().backward()
+    assert pc0.grad.shape == (0, 40, 3) and q0.grad.shape == (0, 4)
+
+
+@pytest.mark.parametrize("case", ["no points, K=1", "no points, K=4", "every point dropped", "no clouds"])
+def test_empty_inputs_through_the_fused_loss(R, O, case):
+    """Zero points per cloud, a dropout that keeps nothing, zero clouds: the fused loss is the loss of empty silhouettes (or
+    0 for an empty batch), gradients are zeros of the inputs' shapes, nothing faults."""
+    G = 32
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    kern = R.smoothing_kernel(cfg, 1.0)
+    K = 4 if "K=4" in case else 1
+    B, N = (0, 50) if case == "no clouds" else (4, 0 if "no points" in case else 50)
+    pc = torch.rand(B, N, 3, device="cuda") - 0.5
+    pc.requires_grad_(True)
+    q = torch.randn(B, 4, device="cuda", requires_grad=True)
+    s = torch.ones(B, 1, device="cuda", requires_grad=True)
+    gt = (torch.rand(B // K, G, G, 1, device="cuda") > 0.5).float()
+    idx = torch.zeros(B, 0, dtype=torch.int32, device="cuda") if case == "every point dropped" else None
+    loss, out, win = R.pointcloud_project_loss(cfg, pc, q, None, None, kern, scaling_factor=s, gt=gt, num_candidates=K, point_index=idx)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert out["proj"].shape == (B, G, G, 1) and win.shape == (B // K,)
+    if B:
+        empty = 1.0 - (1.0 - 1e-5) ** G
+        assert abs(float(out["proj"].max()) - empty) < 1e-7 and abs(float(out["proj"].min()) - empty) < 1e-7
+        want = float(((empty - gt.double()) ** 2).sum() / (B // K))
+        assert abs(float(loss) - want) <= 1e-5 * max(1.0, want)
+    else:
+        assert float(loss) == 0.0
+    assert pc.grad.shape == pc.shape and float(pc.grad.abs().sum()) == 0.0
+    assert q.grad.shape == q.shape and float(q.grad.abs().sum()) == 0.0
 
 
 def test_optional_outputs_of_the_c_abi(R, O, golden):
