@@ -1129,6 +1129,53 @@ def test_empty_inputs_through_the_fused_loss(R, O, case):
     assert q.grad.shape == q.shape and float(q.grad.abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("case", ["only q requires grad", "K=4, one sample, one shared set", "K=2, one sample", "vox_size_z=16",
+                                  "63 taps sigma_rel 8 (staged fallback)", "1 tap", "N=70000 at 64^3"])
+def test_edge_configurations_of_the_fused_loss_vs_oracle(R, O, case):
+    """Corners of the fused call against the oracle: a single sample with K candidates (with and without a shared point
+    set), only the pose needing a gradient, a grid that is shallower than wide, a Gaussian too long for the fused kernels
+    (the call falls back to the staged chain) and a single tap, and a cloud far beyond the flat record table (274 chunks)."""
+    G, ksz, sig, B, N, K, reps, only_q, vz = 32, 11, 0.9, 4, 900, 1, 1, False, None
+    if case == "only q requires grad":
+        only_q = True
+    elif case.startswith("K=4"):
+        K, reps = 4, 4
+    elif case.startswith("K=2"):
+        B, N, K = 2, 700, 2
+    elif case == "vox_size_z=16":
+        B, N, vz = 3, 800, 16
+    elif case.startswith("63 taps"):
+        ksz, sig, B, N = 63, 8.0, 2, 600
+    elif case == "1 tap":
+        ksz, sig, B, N = 1, 0.5, 2, 600
+    else:
+        G, ksz, sig, B, N = 64, 21, 0.64, 1, 70000
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=ksz)
+    if vz is not None:
+        cfg.vox_size_z = vz
+    S = B // reps
+    pc = O.synth_inputs(S, N, G, 11)[0]
+    _, q, s, _, _, _ = O.synth_inputs(B, 4, G, 12)
+    gt = O.synth_inputs(B // K, 1, G, 13)[3]
+    cp, cq, cs = (x.clone().requires_grad_(True) for x in (pc, q, s))
+    ref = O.pointcloud_project_fast(cfg, cp.repeat_interleave(reps, 0) if reps > 1 else cp, cq, None, None,
+                                    O.smoothing_kernel(cfg, sig), scaling_factor=cs)
+    rloss = O.proj_loss_pose_candidates(gt, ref["proj"], K)[0] if K > 1 else ((ref["proj"] - gt) ** 2).sum() / B
+    rloss.backward()
+    gp, gq, gs = dev(pc, not only_q), dev(q, True), dev(s, not only_q)
+    loss, out, _ = R.pointcloud_project_loss(cfg, gp, gq, None, None, R.smoothing_kernel(cfg, sig), scaling_factor=gs, gt=dev(gt),
+                                             num_candidates=K)
+    loss.backward()
+    close(loss, rloss, TOL, case + ": loss")
+    close(out["proj"], ref["proj"], TOL, case + ": proj")
+    close(gq.grad, cq.grad, TOL, case + ": dq")
+    if only_q:
+        assert gp.grad is None and gs.grad is None
+    else:
+        close(gp.grad, cp.grad, TOL, case + ": dpc")
+        close(gs.grad, cs.grad, TOL, case + ": ds")
+
+
 def test_optional_outputs_of_the_c_abi(R, O, golden):
     """dpc_project_fwd called directly: the optional `tr_pc`, `raw` (unclamped splat) and `smoothed` (grid after the
     full Gaussian) outputs against the golden chain, and grid_wh == W/H-smoothed clamp(raw) via the stage kernels."""
