@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DPC_ABI_VERSION 11
+#define DPC_ABI_VERSION 12
 #define DPC_MAX_TAPS 63 /* longest 1-D smoothing kernel accepted (pc_gauss_kernel_size) */
 
 enum {
@@ -44,6 +44,13 @@ enum {
   DPC_ERR_LDS = -4,         /* an H x W plane does not fit the 160 KiB LDS tile (H*W too large) */
   DPC_ERR_LAUNCH = -5,      /* hipLaunchKernel failed (hipGetLastError has the cause) */
   DPC_ERR_UNSUPPORTED = -6  /* configuration the reference itself cannot run (dead branch) */
+};
+
+/* Bits of the optional device status word (DpcParams.status). */
+enum {
+  DPC_STATUS_BAD_INDEX = 1,   /* a point_index entry was outside [0, N_src): the point was dropped (the reference's fancy
+                               * indexing raises IndexError there, dpc/util/point_cloud_to.py:266-295)                   */
+  DPC_STATUS_WAIT_TIMEOUT = 2 /* overlapped step (dpc_step_*): a workgroup gave up waiting for the kernel in front of it  */
 };
 
 /* Geometry and camera constants of one call (dpc/resources/default_config.yaml:77-89 and the cfg fields
@@ -71,7 +78,21 @@ typedef struct DpcParams {
                             * dpc/models/model_pc_to.py:254-258, 302-306; dpc/util/point_cloud_to.py:269-295) without the
                             * [B,N,3] copies.  Then `pc` is [B/R,N_src,3] and `dpc` is [B/R,N_src,3], ZERO-INITIALISED BY
                             * THE CALLER (the selected points' gradients are added into it; indices may repeat).
+                            * An entry outside [0, N_src) never reaches memory: the point is dropped (no contribution, no
+                            * gradient) and DPC_STATUS_BAD_INDEX is set in *status when `status` is given.
                             * Honoured by dpc_locate and the fused entry points; the stage entry points require NULL. */
+  int32_t* status;         /* DEVICE pointer to one int32 | NULL: DPC_STATUS_* bits are OR-ed into it (never cleared by the
+                            * library; the caller zeroes it and reads it at a synchronisation point of its own)           */
+  const int32_t* n_live;   /* DEVICE pointer to one int32 | NULL: only the first min(*n_live, N) points of every cloud (of
+                            * every point_index row) are live in this call, the rest are skipped without a trace.  N stays the
+                            * CAPACITY the buffers and launch grids are sized for -- so a captured HIP graph follows a
+                            * scheduled keep-count (dpc/models/model_pc_to.py:68-87, 254-258) from replay to replay.       */
+  const float* dev_taps_xy; /* DEVICE pointers to taps_xy / taps_z floats | NULL: when given, the kernels read the tap    */
+  const float* dev_taps_z;  /* VALUES from device memory at run time instead of taking them from host_kern_xy / host_kern_z
+                            * at launch time.  The host arrays are still required: they select the compiled radius bucket
+                            * (dpc_taps_bucket) and must need the same bucket as, or a smaller one than, the device values
+                            * ever will.  For captured HIP graphs under a sigma schedule (model_pc_to.py:59-63, 171-179):
+                            * dpc_schedule_update rewrites the device values between replays.                              */
 } DpcParams;
 
 /* Small per-cloud gradients written by the backward entry points: one buffer of DPC_SMALL_COLS * B floats made of
@@ -188,6 +209,21 @@ int dpc_transform_bwd(const DpcParams* p, const float* pc, const float* q, const
  * by the kernel, so a captured graph whose seed words are refreshed by a captured RNG node draws anew at every replay.
  * The result is what DpcParams.point_index expects.  No host work, no synchronisation. */
 int dpc_point_dropout_indices(int B, int N, int n, const int64_t* seed, int32_t* out, void* stream);
+
+/* Schedules under HIP-graph replay (dpc/models/model_pc_to.py:59-87, 171-179, 254-258: sigma_rel(step) and the dropout
+ * keep-probability are recomputed every step).  A captured graph freezes kernel ARGUMENTS, so the per-step values live in
+ * device memory instead: dev_taps_xy[taps_xy], dev_taps_z[taps_z] (DpcParams.dev_taps_*) and n_live[1] (DpcParams.n_live,
+ * the n_live argument of dpc_point_dropout_indices_live).  dpc_schedule_update writes new values with ONE tiny launch on
+ * `stream` (the values travel as kernel arguments: no pinned staging buffer, nothing to keep alive); enqueue it in front of
+ * every replay.  Any of the three destinations may be NULL.  dpc_taps_bucket: the compiled radius bucket a 1-D kernel needs
+ * (after dropping outer taps that cannot change an fp32 result), -1 when it is beyond the fused kernels -- a captured graph
+ * stays valid while the bucket of the new taps is <= the bucket it was captured with, and is fastest when equal. */
+int dpc_schedule_update(const float* host_kern_xy, int taps_xy, const float* host_kern_z, int taps_z, int n_live,
+                        float* dev_taps_xy, float* dev_taps_z, int32_t* dev_n_live, void* stream);
+int dpc_taps_bucket(const float* host_kern, int taps);
+/* dpc_point_dropout_indices with the keep-count read on the device: rows of `n` slots (the capacity), the first
+ * min(*n_live, n) of each filled, ascending.  n_live NULL = n. */
+int dpc_point_dropout_indices_live(int B, int N, int n, const int32_t* n_live, const int64_t* seed, int32_t* out, void* stream);
 
 /* pointcloud2voxels3d_fast (dpc/util/point_cloud_to.py:10-87): trilinear scatter of already-transformed
  * points tr [B,N,3] (z,y,x; fp32, or fp64 when tr_is_f64 -- the reference's direct callers pass fp64) into

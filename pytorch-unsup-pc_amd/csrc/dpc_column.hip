@@ -80,9 +80,10 @@ __device__ inline void zcol_fwd_epilogue(const DpcParams& P, const RayConst& rc,
 
 template <int DD, int RB>
 __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_fwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf,
-                                                          const float* __restrict__ s, TapsT<RB> taps,
+                                                          const float* __restrict__ s, TapsT<RB> taps_arg,
                                                           float* __restrict__ smoothed, float* __restrict__ proj,
                                                           float* __restrict__ trans_out, LossArgs la) {
+  const TapsT<RB> taps = resolve_taps<RB>(taps_arg, P.dev_taps_z, P.taps_z, false);
   const int HW = P.H * P.W;
   const Blk bk = block_coords(P.B);
   const int b = bk.y, ray = bk.x * kColThreads + threadIdx.x;
@@ -131,11 +132,13 @@ __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_fwd(Dp
 #endif
 template <int DD, int RB, int RPL>
 __global__ __launch_bounds__(kColThreads, (RPL * DD <= DPC_ZFB_2WAVE_MAX ? 2 : 1))
-void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, const float* __restrict__ s, TapsT<RB> taps,
-                   TapsT<RB> taps_adj, float* __restrict__ proj, float* __restrict__ dT, float* __restrict__ ds_part,
+void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, const float* __restrict__ s, TapsT<RB> taps_arg,
+                   TapsT<RB> taps_adj_arg, float* __restrict__ proj, float* __restrict__ dT, float* __restrict__ ds_part,
                    int n_ds_part, unsigned long long* __restrict__ tickets, SseFormat cf, SseFormat bf, float* __restrict__ dsmall,
                    unsigned int* __restrict__ cg_count, LossArgs la) {
   typedef float vec __attribute__((ext_vector_type(RPL)));
+  const TapsT<RB> taps = resolve_taps<RB>(taps_arg, P.dev_taps_z, P.taps_z, false);
+  const TapsT<RB> taps_adj = resolve_taps<RB>(taps_adj_arg, P.dev_taps_z, P.taps_z, true);
   const int HW = P.H * P.W;
   const Blk bk = block_coords(P.B);
   const int b = bk.y, ray = RPL * (bk.x * kColThreads + threadIdx.x);
@@ -305,9 +308,10 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
 
 // Generic depth / tap count: same arithmetic, column re-read from global (L1/L2 serve the re-reads).
 __global__ __launch_bounds__(kColThreads) void k_zcol_fwd_dyn(DpcParams P, RayHost rh, const float* __restrict__ Tbuf,
-                                                              const float* __restrict__ s, TapsDyn taps,
+                                                              const float* __restrict__ s, TapsDyn taps_arg,
                                                               float* __restrict__ smoothed, float* __restrict__ proj,
                                                               float* __restrict__ trans_out, LossArgs la) {
+  const TapsDyn taps = resolve_taps_dyn(taps_arg, P.dev_taps_z, false);
   const int HW = P.H * P.W, D = P.D;
   const Blk bk = block_coords(P.B);
   const int b = bk.y, ray = bk.x * kColThreads + threadIdx.x;
@@ -379,11 +383,13 @@ template <int DD, int RB>
 __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHost rh, const float* __restrict__ Tin,
                                                           const float* __restrict__ s,
                                                           const float* __restrict__ dproj, const float* __restrict__ proj,
-                                                          const float* __restrict__ trans_in, TapsT<RB> taps,
-                                                          TapsT<RB> taps_adj,
+                                                          const float* __restrict__ trans_in, TapsT<RB> taps_arg,
+                                                          TapsT<RB> taps_adj_arg,
                                                           float* __restrict__ dT, float* __restrict__ ds_part,
                                                           float* __restrict__ dsmall, unsigned int* __restrict__ cg_count,
                                                           const float* __restrict__ dgrid_extra, LossArgs la) {
+  const TapsT<RB> taps = resolve_taps<RB>(taps_arg, P.dev_taps_z, P.taps_z, false);
+  const TapsT<RB> taps_adj = resolve_taps<RB>(taps_adj_arg, P.dev_taps_z, P.taps_z, true);
   const int HW = P.H * P.W;
   const bool wo = winners_only(la);  // grid over samples: this workgroup works on the winning candidate of sample bk.y
   const Blk bk = block_coords(wo ? P.B / la.K : P.B);
@@ -451,11 +457,12 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
 __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHost rh, const float* __restrict__ Tin,
                                                               const float* __restrict__ s,
                                                               const float* __restrict__ dproj, const float* __restrict__ proj,
-                                                              const float* __restrict__ trans_in, TapsDyn taps,
-                                                              TapsDyn taps_adj,
+                                                              const float* __restrict__ trans_in, TapsDyn taps_arg,
+                                                              TapsDyn taps_adj_arg,
                                                               float* __restrict__ dT, float* __restrict__ ds_part,
                                                               float* __restrict__ dsmall, unsigned int* __restrict__ cg_count,
                                                               const float* __restrict__ dgrid_extra, LossArgs la) {
+  const TapsDyn taps = resolve_taps_dyn(taps_arg, P.dev_taps_z, false), taps_adj = resolve_taps_dyn(taps_adj_arg, P.dev_taps_z, true);
   const int HW = P.H * P.W, D = P.D;
   const bool wo = winners_only(la);  // grid over samples: this workgroup works on the winning candidate of sample bk.y
   const Blk bk = block_coords(wo ? P.B / la.K : P.B);

@@ -22,6 +22,33 @@ struct TapsDyn {
   int n;  // number of taps (odd) or 0
 };
 
+// Tap VALUES from device memory (DpcParams.dev_taps_*: a captured HIP graph under a sigma schedule, include/dpc_render.h).
+// `host` came with the launch and fixed the radius bucket RB; when `dev` is given, every tap of the n-tap kernel that falls
+// inside the compiled window replaces it (uniform addresses: scalar loads, the weights stay in SGPRs).  flip: the adjoint
+// (correlation with the reversed kernel).
+template <int RB>
+__device__ inline TapsT<RB> resolve_taps(const TapsT<RB>& host, const float* __restrict__ dev, int n, bool flip) {
+  if (dev == nullptr || n <= 0) return host;
+  TapsT<RB> t;
+  const int c = (n - 1) / 2;
+#pragma unroll
+  for (int i = 0; i < 2 * RB + 1; ++i) {
+    const int o = i - RB, src = c + (flip ? -o : o);
+    float w = 0.f;
+    if (src >= 0 && src < n) w = dev[src];
+    t.w[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(w)));
+  }
+  return t;
+}
+
+__device__ inline TapsDyn resolve_taps_dyn(const TapsDyn& host, const float* __restrict__ dev, bool flip) {
+  if (dev == nullptr || host.n <= 0) return host;
+  TapsDyn t;
+  t.n = host.n;
+  for (int i = 0; i < DPC_MAX_TAPS; ++i) t.w[i] = i < host.n ? dev[flip ? host.n - 1 - i : i] : 0.f;
+  return t;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Camera: p -> (z, y, x) = (p'_0, f p'_1 / (p'_0 + d), f p'_2 / (p'_0 + d)),  p' = R(q/|q|) p + t
 // (dpc/util/point_cloud_to.py:135-148,169-177; dpc/util/quaternion.py:110-132)

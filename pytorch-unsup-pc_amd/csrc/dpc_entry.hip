@@ -15,6 +15,11 @@ extern "C" int dpc_debug_set_stamps(void* p) { return dpc_debug_set_stamps_fwd(p
 
 extern "C" {
 
+int dpc_taps_bucket(const float* host_kern, int taps) {
+  if (taps < 0 || taps > DPC_MAX_TAPS || (taps > 0 && (taps % 2 == 0 || !host_kern))) return -1;
+  return plan_taps(host_kern, taps).bucket;
+}
+
 size_t dpc_mask_words_per_plane(const DpcParams* p) { return p ? ((size_t)p->H * p->W + 63) / 64 : 0; }
 
 size_t dpc_cells_bytes(const DpcParams* p) {

@@ -1,5 +1,6 @@
 // Shared by the kernel files of libdpc_render.so: layouts, LDS pass helpers, host-side launch plumbing.
 //   dpc_slab_fwd.hip   k_locate, k_splat_hw            (transform + cell location, splat + W/H passes)
+//   dpc_slab_xl.hip    k_splat_xl                      (the same slab work with x in the lanes, 64-wide grids)
 //   dpc_column.hip     k_zcol_fwd / _bwd / _fwdbwd     (D pass, DRC ray march and its backward, loss finalize)
 //   dpc_slab_bwd.hip   k_gather_hw                     (adjoint H/W passes, 8-corner gather, transform backward)
 //   dpc_entry.hip      C ABI of the fused path
@@ -634,6 +635,7 @@ inline int validate(const DpcParams* p) {
   if (p->D > 1024 || p->H > 1024 || p->W > 1024 || p->B > 65535) return DPC_ERR_SHAPE;  // 10-bit cell indices
   if (p->point_replicas < 0 || (p->point_replicas > 1 && p->B % p->point_replicas != 0)) return DPC_ERR_SHAPE;
   if (p->point_index != nullptr && p->N_src < 1) return DPC_ERR_SHAPE;
+  if ((p->dev_taps_xy != nullptr && p->taps_xy < 1) || (p->dev_taps_z != nullptr && p->taps_z < 1)) return DPC_ERR_TAPS;
   for (int taps : {p->taps_xy, p->taps_z})
     if (taps < 0 || taps > DPC_MAX_TAPS || (taps > 0 && taps % 2 == 0)) return DPC_ERR_TAPS;
   return DPC_OK;
@@ -818,8 +820,5 @@ int launch_loss_finalize(const float* sse_tiles, int ntile, float* sse, int S, i
 bool xl_applies(const DpcParams* p, int bucket);
 int launch_splat_xl(int bucket, const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* Tbuf, uint64_t* mask,
                     float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st);
-int launch_gather_xl(int bucket, const DpcParams* p, Cells cells, const float* q, const float* t, const float* f, const float* kxy,
-                     const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part, int ntile, float* dpc,
-                     float* dsmall, double* cg_part, unsigned int* cg_count, const LossArgs& la, hipStream_t st);
 
 }  // namespace dpck

@@ -14,7 +14,7 @@ namespace {
 template <int GS, int ZS, int RB>
 __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells cells, const float* __restrict__ pc,
                                                             const float* __restrict__ q, const float* __restrict__ t,
-                                                            const float* __restrict__ f, TapsT<RB> taps_adj, int zs_rt,
+                                                            const float* __restrict__ f, TapsT<RB> taps_arg, int zs_rt,
                                                             const float* __restrict__ dT,
                                                             const uint64_t* __restrict__ mask,
                                                             const float* __restrict__ ds_part, int n_ds_part,
@@ -22,6 +22,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
                                                             double* __restrict__ cg_part,
                                                             unsigned int* __restrict__ cg_count, LossArgs la) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
+  const TapsT<RB> taps_adj = resolve_taps<RB>(taps_arg, P.dev_taps_xy, P.taps_xy, true);
   const int D = P.D, H = P.H, W = P.W, HW = H * W;
   const int Zs = GS ? ZS : zs_rt;
   // One-layer slabs (planes too big for more: 128^2) ROLL: the workgroup walks `roll` consecutive layers, keeps the plane
@@ -38,7 +39,8 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   // ... and when a point set belongs to the K candidates of ONE sample, its single winner is the only cloud that ever
   // writes into the set's gradient: plain stores then (float atomics to 24 000 scattered addresses tripled the gather
   // phase of the c5 winners: 11.4 -> 3.9 us)
-  const bool single_writer = wo && reps == la.K;
+  // (not with a point_index: its rows may repeat an index, and two contributions to one point must be summed)
+  const bool single_writer = wo && reps == la.K && P.point_index == nullptr;
   const Blk bk = block_coords(wo ? P.B / la.K : P.B, la.winner != nullptr ? la.K : 1);
   const int b = wo ? bk.y * la.K + la.winner[bk.y] : bk.y, z0 = bk.x * Zs * roll;
   const int Nset = points_per_set(P);
@@ -349,11 +351,6 @@ int launch_gather_rb(const DpcParams* p, Cells cells, const float* pc, const flo
 int launch_gather(int bucket, const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
                   const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part, int ntile,
                   float* dpc, float* dsmall, double* cg_part, unsigned int* cg_count, const LossArgs& la, hipStream_t st) {
-#ifdef DPC_XL_GATHER  // measured: its gather phase is 1.3 us shorter (8 reads per point instead of 32 + mask), its dT load
-                      // phase 2.8 us longer (4-byte loads at one x per lane against 8-byte column pairs): not the default
-  if (xl_applies(p, bucket))
-    return launch_gather_xl(bucket, p, cells, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
-#endif
   int rc = DPC_OK;
 #define DPC_GATHER(RB) rc = launch_gather_rb<RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st)
   DPC_FOR_BUCKET(bucket, DPC_GATHER)

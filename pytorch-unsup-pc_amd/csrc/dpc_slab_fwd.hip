@@ -29,7 +29,10 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
   const int b = bk.y, blk = bk.x, tid = threadIdx.x;
   const int D = P.D, nbins = D + 1;
   const int i = blk * kLocThreads + tid;
-  const bool live = i < P.N;
+  // N is the capacity of the call; a device-side count of live points (a scheduled keep-count under graph replay) may cut
+  // it short: the points beyond it become out-of-bounds records (bin D) that no later kernel looks at
+  const int n_live = P.n_live != nullptr ? min(P.N, *P.n_live) : P.N;
+  const bool present = i < P.N, live = i < n_live;
   constexpr int MW = kLocThreads / 32;  // mask words per bin
   for (int k = tid; k < nbins * MW; k += kLocThreads) member[k] = 0u;
   // every thread normalises the quaternion itself (a dozen fp32 ops): cheaper than one thread doing it while 255 wait
@@ -45,10 +48,22 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
     double Z, Y, X;
     if (SRC == 0) {
       const int reps = P.point_replicas > 1 ? P.point_replicas : 1;  // replicas of one point set read the same rows
-      if (P.point_index != nullptr) src_i = P.point_index[idx];       // this cloud's own subset of the stored set
+      bool in_set = true;
+      if (P.point_index != nullptr) {   // this cloud's own subset of the stored set
+        src_i = P.point_index[idx];
+        // an index outside the stored set never becomes an address (the reference's fancy indexing raises IndexError,
+        // point_cloud_to.py:266-295): the point is dropped -- an out-of-bounds record at source index 0, which neither the
+        // forward nor the backward touches -- and the caller's status word says so
+        in_set = (unsigned)src_i < (unsigned)P.N_src;
+        if (!in_set) {
+          src_i = 0;
+          if (P.status != nullptr) atomicOr(P.status, (int)DPC_STATUS_BAD_INDEX);
+        }
+      }
       const float* p = static_cast<const float*>(pts) + ((size_t)(b / reps) * points_per_set(P) + src_i) * 3;
       src_pt[0] = p[0]; src_pt[1] = p[1]; src_pt[2] = p[2];
       project_point_ref(cam_s, p[0], p[1], p[2], Z, Y, X);
+      if (!in_set) Z = Y = X = 2.0;   // outside [-1/2, 1/2]^3: make_record marks it out of bounds
       if (tr_pc != nullptr) {
         tr_pc[idx * 3 + 0] = (float)Z; tr_pc[idx * 3 + 1] = (float)Y; tr_pc[idx * 3 + 2] = (float)X;
       }
@@ -61,9 +76,10 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
     }
     rec = make_record(Z, Y, X, P.D, P.H, P.W);
   }
+  if (present && !live && P.point_index != nullptr) src_i = 0;   // a skipped point: an out-of-bounds record at a valid source index
   const int bin = rec.code < 0 ? D : (rec.code >> 20);
   __syncthreads();  // the masks are zeroed (the transform above ran under that latency)
-  if (live) atomicOr(&member[bin * MW + (tid >> 5)], 1u << (tid & 31));
+  if (present) atomicOr(&member[bin * MW + (tid >> 5)], 1u << (tid & 31));
   __syncthreads();
 
   // exclusive prefix over the bin populations by the first wave: lane l owns bins [l*C, (l+1)*C)
@@ -94,7 +110,7 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
 
   // sorted chunk staged in LDS, then copied out with one coalesced 16-byte store per lane and array
   __shared__ int4 stage[2 * kLocThreads];
-  if (live) {
+  if (present) {
     int below = 0;  // members of this bin with a smaller thread id
 #pragma unroll
     for (int wd = 0; wd < MW; ++wd) {
@@ -127,12 +143,13 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
 //   Tbuf == nullptr: stage-level pointcloud2voxels3d_fast, only `raw` is written.
 // ------------------------------------------------------------------------------------------------------
 template <int GS, int ZS, int RB>
-__global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells cells, TapsT<RB> taps, int zs_rt,
+__global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells cells, TapsT<RB> taps_arg, int zs_rt,
                                                            float* __restrict__ raw, float* __restrict__ Tbuf,
                                                            uint64_t* __restrict__ mask, float* __restrict__ sse,
                                                            float* __restrict__ loss_zero, int* __restrict__ winner_zero,
                                                            unsigned long long* __restrict__ ticket_zero) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
+  const TapsT<RB> taps = resolve_taps<RB>(taps_arg, P.dev_taps_xy, P.taps_xy, false);
   const Blk bk = block_coords(P.B);
   if (sse != nullptr && bk.x == 0 && threadIdx.x == 0) {  // k_zcol_fwd accumulates into these
     sse[bk.y] = 0.f;

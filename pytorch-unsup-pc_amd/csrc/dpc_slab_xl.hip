@@ -1,4 +1,4 @@
-// Slab kernels for 64-wide grids with x in the lanes (k_splat_xl, k_gather_xl).  Design notes: DESIGN.md section 4.
+// Forward slab kernel for 64-wide grids with x in the lanes (k_splat_xl).  Design notes: DESIGN.md section 4.
 //
 // A grid row of 64 voxels is exactly one wavefront, so a thread that owns a run of y at ONE x gets
 //   * the H pass in registers (a window along y, read with lanes on consecutive x: coalesced from global, conflict-free
@@ -7,9 +7,9 @@
 //     the correlation at both ends of the row) -- no LDS round trip and no barrier between the two passes,
 //   * the clamp mask for free: the 64 mask bits of a grid row ARE a 64-bit lane mask (forward: the SGPR pair a v_cmp
 //     writes; backward: a scalar load used as the select mask of a v_cndmask).
-// The forward needs no fp32 copy of the slab at all (accumulators -> registers -> global); the backward leaves the fully
-// adjoint-filtered, masked d(raw) in LDS, so a point gathers its 8 corners with 8 reads (the kernels these replace
-// evaluated the adjoint W pass at every gathered corner: 32 reads + a mask lookup per point).
+// The forward needs no fp32 copy of the slab at all (accumulators -> registers -> global).  (A backward on the same plan --
+// d(raw) fully filtered in LDS, 8 reads per gathered point -- measured slower than k_gather_hw in round 2: its dT load phase
+// is 4-byte loads at one x per lane against 8-byte column pairs; it was removed in round 3, git history has it.)
 #include "dpc_kernels.h"
 
 DPC_DEBUG_SETTERS(xl)
@@ -19,7 +19,6 @@ namespace {
 
 constexpr int kXG = 64;     // H = W = 64: one wave per grid row
 constexpr int kXSeg = 16;   // y outputs per thread
-constexpr int kXSegs = kXG / kXSeg;
 
 template <int CTRL>
 __device__ inline float dpp_zero_fill(float v) {
@@ -68,13 +67,14 @@ __device__ inline float wpass_lanes(float v, const TapsT<RB>& taps) {
 //   accumulator planes carry RB zero rows above and below (the zero padding of the H pass)
 // ------------------------------------------------------------------------------------------------------
 template <int ZS, int RB>
-__global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells, TapsT<RB> taps, float* __restrict__ Tbuf,
+__global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells, TapsT<RB> taps_arg, float* __restrict__ Tbuf,
                                                        uint64_t* __restrict__ mask, float* __restrict__ sse,
                                                        float* __restrict__ loss_zero, int* __restrict__ winner_zero,
                                                        unsigned long long* __restrict__ ticket_zero) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
   constexpr int NT = ZS * 256, PR = kXG + 2 * RB, ACC = ZS * PR * kXG, WIN = kXSeg + 2 * RB;
   static_assert(ACC % 4 == 0, "zero fill in 16-byte words, two halves");
+  const TapsT<RB> taps = resolve_taps<RB>(taps_arg, P.dev_taps_xy, P.taps_xy, false);
   const Blk bk = block_coords(P.B);
   if (sse != nullptr && bk.x == 0 && threadIdx.x == 0) {  // the ray-march kernel accumulates into these
     sse[bk.y] = 0.f;
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells,
       o[e] = wpass_lanes<RB>(h, taps);
     }
     quad_transpose(o, lane);
-    if (!DPC_ABL(5) || o[0] == 123.456f) *reinterpret_cast<f32x4*>(Tout + (size_t)j * kXG) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(Tout + (size_t)j * kXG) = f32x4{o[0], o[1], o[2], o[3]};
   }
   DPC_STAMP(5);
 }
@@ -200,184 +200,6 @@ int launch_splat_xl_zr(const DpcParams* p, Cells cells, const float* kxy, const 
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_splat_xl", kern, dim3(((p->D + ZS - 1) / ZS) * p->B), dim3(ZS * 256), lds, st, *p, cells,
              make_taps<RB>(kxy, pxy, false), Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
-  return launch_ok();
-}
-
-// ------------------------------------------------------------------------------------------------------
-// Backward: per thread a y window of dT at one x straight from global -> adjoint H pass in registers -> adjoint W pass
-// across lanes -> clamp mask as the select mask -> d(raw) in LDS; then the 8-corner gather, the transform backward and
-// the fixed-order camera-gradient sums of k_gather_hw.                               grid (D/ZS) x B, 1024 threads
-// ------------------------------------------------------------------------------------------------------
-template <int ZS, int RB>
-__global__ __launch_bounds__(kSlabThreads) void k_gather_xl(DpcParams P, Cells cells, const float* __restrict__ q,
-                                                            const float* __restrict__ t, const float* __restrict__ f,
-                                                            TapsT<RB> taps_adj, const float* __restrict__ dT,
-                                                            const uint64_t* __restrict__ mask,
-                                                            const float* __restrict__ ds_part, int n_ds_part,
-                                                            float* __restrict__ dpc, float* __restrict__ dsmall,
-                                                            double* __restrict__ cg_part,
-                                                            unsigned int* __restrict__ cg_count, LossArgs la) {
-  extern __shared__ __attribute__((aligned(16))) float slab[];
-  constexpr int NPL = ZS + 1, NT = kSlabThreads, NW = NT / DPC_WAVE, WIN = kXSeg + 2 * RB;
-  constexpr int NITEM = NPL * kXSegs, IPT = (NITEM + NW - 1) / NW;   // 36 items, 3 per wave on 12 of the 16 waves
-  const int D = P.D;
-  const Blk bk = block_coords(P.B);
-  const int b = bk.y, z0 = bk.x * ZS;
-  const int reps = P.point_replicas > 1 ? P.point_replicas : 1;
-  // replicas of a point set, or clouds that picked their points out of a stored set: dpc is [B/reps,Nset,3], zeroed by the
-  // caller, and every cloud ADDS its gradients into it
-  const bool shared_points = reps > 1 || P.point_index != nullptr;
-  const int Nset = points_per_set(P);
-  const int tid = threadIdx.x;
-  if (cloud_loses(la, b)) {  // a losing pose candidate: zero gradient, no work (block-uniform)
-    if (shared_points) {
-      if (bk.x == 0 && tid == 0) dsmall[(size_t)DPC_COL_DS * P.B + b] = 0.f;
-      return;
-    }
-    float* dz = dpc + (size_t)b * Nset * 3;
-    auto zero3 = [&](const PointRec&, const int4* aux) {
-      const int i = aux->w;
-      dz[3 * i + 0] = 0.f; dz[3 * i + 1] = 0.f; dz[3 * i + 2] = 0.f;
-    };
-    for_each_record(cells, b, z0, min(z0 + ZS, D), zero3);
-    if (bk.x == 0) {
-      for_each_record(cells, b, D, D + 1, zero3);
-      if (tid == 0) dsmall[(size_t)DPC_COL_DS * P.B + b] = 0.f;
-    }
-    return;
-  }
-  const int nzp = min(NPL, D - z0);  // planes present (cell layers + halo)
-  const CameraRaw cam_raw = load_camera_raw(P, q, t, f, b);
-  const float upstream = (la.scale_in_gather && la.dloss != nullptr) ? *la.dloss : 1.0f;
-  const float* src = dT + ((size_t)b * D + z0) * kXG * kXG;
-  const unsigned long long* mrow = reinterpret_cast<const unsigned long long*>(mask) + ((size_t)b * D + z0) * kXG;
-  int* tab = reinterpret_cast<int*>(slab + NPL * kXG * kXG);
-  const bool flat = cells.nblk <= DPC_WAVE;
-  RecordRange rr{0, 0};
-  if (flat) rr = load_record_range(cells, b, z0, min(z0 + ZS, D));  // in flight under the plane loads
-  DPC_STAMP(8);
-
-  // items = (plane z, rows y0 .. y0+15), one wave each: NPL x 4 items over the first NPL x 4 / IPT waves, IPT each, in
-  // straight-line code -- every load of the wave is requested up front (rows outside the plane re-read an edge row and are
-  // zeroed by a select: no branch per load, so the waits are counted per item and item k is filtered while k+1.. arrive).
-  // The 16 clamp-mask words of an item are ONE 8-byte load (lane j holds row j's word), read back lane by lane.
-  const int lane = tid & (DPC_WAVE - 1);
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  static_assert(NITEM % IPT == 0 && NITEM / IPT <= NW, "whole items per wave");
-  if (w < NITEM / IPT) {
-    float win[IPT][WIN];
-    unsigned long long mwords[IPT];
-#pragma unroll
-    for (int it = 0; it < IPT; ++it) {
-      const int item = w * IPT + it;
-      const int z = item / kXSegs, y0 = (item % kXSegs) * kXSeg;
-      const int zc = min(z, nzp - 1);  // planes beyond the grid: valid addresses, values dropped below
-#pragma unroll
-      for (int i = 0; i < WIN; ++i) {
-        const int y = y0 - RB + i;
-        const float val = src[((size_t)zc * kXG + min(max(y, 0), kXG - 1)) * kXG + lane];
-        win[it][i] = (z < nzp && y >= 0 && y < kXG) ? val : 0.f;
-      }
-      mwords[it] = mrow[(size_t)zc * kXG + y0 + (lane & (kXSeg - 1))];
-    }
-#pragma unroll
-    for (int it = 0; it < IPT; ++it) {
-      const int item = w * IPT + it;
-      const int z = item / kXSegs, y0 = (item % kXSegs) * kXSeg;
-      float* out = slab + ((size_t)z * kXG + y0) * kXG + lane;
-      const unsigned int mlo = (unsigned int)mwords[it], mhi = (unsigned int)(mwords[it] >> 32);
-#pragma unroll
-      for (int j = 0; j < kXSeg; ++j) {
-        float h = 0.f;
-#pragma unroll
-        for (int tp = 0; tp < 2 * RB + 1; ++tp) h = fmaf(taps_adj.w[tp], win[it][j + tp], h);
-        float o = wpass_lanes<RB>(h, taps_adj);
-        // the row's mask word is this wave's lane mask: one select
-        const unsigned long long bits = ((unsigned long long)(unsigned int)__builtin_amdgcn_readlane((int)mhi, j) << 32) |
-                                        (unsigned int)__builtin_amdgcn_readlane((int)mlo, j);
-        asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(o) : "v"(o), "s"(bits));
-        out[(size_t)j * kXG] = o;
-      }
-    }
-  }
-  if (flat) finish_record_table(rr, tab);
-  __syncthreads();
-  DPC_STAMP(9);
-
-  const Camera cam = make_camera(P, cam_raw);
-  CamGrad g;
-  camgrad_zero(g);
-  float* dcloud = dpc + (size_t)(b / reps) * Nset * 3;
-  auto gather = [&](const PointRec& rec, const int4* aux) {
-    const int4 pt = *aux;  // {px, py, pz, original index}
-    const int i = pt.w;
-    const Cell c = cell_from_record(rec);
-    float cv[2][2][2];
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const bool ok = (c.iz + k < D) && (c.iy + j < kXG) && (c.ix + e < kXG);
-          cv[k][j][e] = ok ? slab[((c.iz - z0 + k) * kXG + c.iy + j) * kXG + c.ix + e] : 0.f;
-        }
-    float dgz = 0.f, dgy = 0.f, dgx = 0.f;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        dgz += (cv[1][a][e] - cv[0][a][e]) * c.wy[a] * c.wx[e];
-        dgy += (cv[a][1][e] - cv[a][0][e]) * c.wz[a] * c.wx[e];
-        dgx += (cv[a][e][1] - cv[a][e][0]) * c.wz[a] * c.wy[e];
-      }
-    dgz *= upstream; dgy *= upstream; dgx *= upstream;  // 1 unless dT was produced by the forward for dloss = 1
-    const float px = __int_as_float(pt.x), py = __int_as_float(pt.y), pz = __int_as_float(pt.z);
-    const Projected o = project_point(cam, px, py, pz);
-    float dpx, dpy, dpz;
-    project_point_bwd(cam, o, px, py, pz, dgz * (float)(D - 1), dgy * (float)(kXG - 1), dgx * (float)(kXG - 1), dpx, dpy, dpz, g);
-    if (shared_points) {
-      atomicAdd(dcloud + 3 * i + 0, dpx); atomicAdd(dcloud + 3 * i + 1, dpy); atomicAdd(dcloud + 3 * i + 2, dpz);
-    } else {
-      dcloud[3 * i + 0] = dpx; dcloud[3 * i + 1] = dpy; dcloud[3 * i + 2] = dpz;
-    }
-  };
-  if (flat) for_each_record_flat(cells, b, tab, gather);
-  else for_each_record(cells, b, z0, min(z0 + ZS, D), gather);
-  DPC_STAMP(11);
-  if (bk.x == 0 && !shared_points)  // the out-of-bounds points (bin D) get a zero gradient
-    for_each_record(cells, b, D, D + 1, [&](const PointRec&, const int4* aux) {
-      const int i = aux->w;
-      dcloud[3 * i + 0] = 0.f; dcloud[3 * i + 1] = 0.f; dcloud[3 * i + 2] = 0.f;
-    });
-
-  float vals[13];
-#pragma unroll
-  for (int i = 0; i < 9; ++i) vals[i] = g.m[i];
-  vals[9] = g.dt[0]; vals[10] = g.dt[1]; vals[11] = g.dt[2]; vals[12] = g.df;
-  const double tot = block_sum13_fixed(vals, reinterpret_cast<float*>(tab + kTabInts), tid, NT);
-  DPC_STAMP(12);
-  if (tid == 0 && bk.x == 0) {  // the occupancy-scale gradient: the column kernel's per-tile partials, in tile order
-    float ds = 0.f;
-    for (int i = 0; i < n_ds_part; ++i) ds += ds_part[(size_t)b * n_ds_part + i];
-    dsmall[(size_t)DPC_COL_DS * P.B + b] = ds * upstream;
-  }
-  camgrad_publish(tot, tid, cam_raw, P.B, b, bk.x, bk.nx, cg_part, cg_count, dsmall, t != nullptr, f != nullptr);
-  DPC_STAMP(13);
-}
-
-template <int ZS, int RB>
-int launch_gather_xl_zr(const DpcParams* p, Cells cells, const float* q, const float* t, const float* f, const float* kxy,
-                        const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part, int ntile, float* dpc,
-                        float* dsmall, double* cg_part, unsigned int* cg_count, const LossArgs& la, hipStream_t st) {
-  constexpr size_t lds = (size_t)(ZS + 1) * kXG * kXG * sizeof(float) + kTabInts * sizeof(int) + camgrad_scratch_bytes(kSlabThreads);
-  static_assert(lds <= kLdsLimit, "backward slab does not fit LDS");
-  auto kern = k_gather_xl<ZS, RB>;
-  static LdsLimit limit;
-  int rc = set_lds(kern, lds, limit);
-  if (rc != DPC_OK) return rc;
-  DPC_LAUNCH("k_gather_hw", kern, dim3(((p->D + ZS - 1) / ZS) * p->B), dim3(kSlabThreads), lds, st, *p, cells, q, t, f,
-             make_taps<RB>(kxy, pxy, true), dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la);
   return launch_ok();
 }
 
@@ -400,19 +222,6 @@ int launch_splat_xl(int bucket, const DpcParams* p, Cells cells, const float* kx
     case 3: return launch_splat_xl_zr<ZS, 3>(p, cells, kxy, pxy, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
     case 4: return launch_splat_xl_zr<ZS, 4>(p, cells, kxy, pxy, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
     case 6: return launch_splat_xl_zr<ZS, 6>(p, cells, kxy, pxy, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
-  }
-  return DPC_ERR_TAPS;
-}
-
-int launch_gather_xl(int bucket, const DpcParams* p, Cells cells, const float* q, const float* t, const float* f, const float* kxy,
-                     const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part, int ntile, float* dpc,
-                     float* dsmall, double* cg_part, unsigned int* cg_count, const LossArgs& la, hipStream_t st) {
-  switch (bucket) {
-    case 1: return launch_gather_xl_zr<8, 1>(p, cells, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
-    case 2: return launch_gather_xl_zr<8, 2>(p, cells, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
-    case 3: return launch_gather_xl_zr<8, 3>(p, cells, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
-    case 4: return launch_gather_xl_zr<8, 4>(p, cells, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
-    case 6: return launch_gather_xl_zr<8, 6>(p, cells, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
   }
   return DPC_ERR_TAPS;
 }

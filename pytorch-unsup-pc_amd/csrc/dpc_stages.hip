@@ -17,6 +17,7 @@ int validate(const DpcParams* p) {
   if (p->point_replicas < 0 || p->point_replicas > 1 || p->point_index != nullptr) return DPC_ERR_SHAPE;  // shared / indexed point sets: fused entry points only
   for (int taps : {p->taps_xy, p->taps_z})
     if (taps < 0 || taps > DPC_MAX_TAPS || (taps > 0 && taps % 2 == 0)) return DPC_ERR_TAPS;
+  if ((p->dev_taps_xy != nullptr && p->taps_xy < 1) || (p->dev_taps_z != nullptr && p->taps_z < 1)) return DPC_ERR_TAPS;
   return DPC_OK;
 }
 
@@ -123,7 +124,9 @@ __global__ __launch_bounds__(kThreads) void k_splat_bwd(DpcParams P, const TIN* 
 //   element (o, i, r): outer index o, position i along the axis (length len, stride `inner`), inner index r
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kThreads) void k_conv_axis(const float* __restrict__ in, float* __restrict__ out,
-                                                        size_t total, int len, int inner, TapsDyn taps) {
+                                                        size_t total, int len, int inner, TapsDyn taps_arg,
+                                                        const float* __restrict__ dev_taps, int flip) {
+  const TapsDyn taps = resolve_taps_dyn(taps_arg, dev_taps, flip != 0);   // DpcParams.dev_taps_*: values from device memory
   const int R = (taps.n - 1) / 2;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     const int i = (int)((e / inner) % len);
@@ -285,8 +288,11 @@ __device__ inline uint32_t dropout_key(uint64_t s0, uint64_t s1, int cloud, int 
   return (uint32_t)(x >> 32);
 }
 
-__global__ __launch_bounds__(kDropThreads) void k_dropout_indices(int N, int n, const int64_t* __restrict__ seed,
+// n_cap: slots per output row; n_live (device, may be NULL): how many of them to fill in this launch
+__global__ __launch_bounds__(kDropThreads) void k_dropout_indices(int N, int n_cap, const int32_t* __restrict__ n_live,
+                                                                  const int64_t* __restrict__ seed,
                                                                   int32_t* __restrict__ out) {
+  const int n = n_live != nullptr ? min(max(*n_live, 0), n_cap) : n_cap;
   __shared__ int hist[256];
   __shared__ uint32_t sel_prefix;
   __shared__ int sel_remaining;
@@ -319,7 +325,7 @@ __global__ __launch_bounds__(kDropThreads) void k_dropout_indices(int N, int n, 
   const int take_equal = sel_remaining;   // how many of the keys == T are kept (>= 1 when n > 0)
   if (tid == 0) { base_out = 0; base_equal = 0; }
   __syncthreads();
-  int32_t* row = out + (size_t)b * n;
+  int32_t* row = out + (size_t)b * n_cap;
   for (int i0 = 0; i0 < N; i0 += kDropThreads) {
     const int i = i0 + tid;
     const uint32_t k = i < N ? dropout_key(s0, s1, b, i) : 0xFFFFFFFFu;
@@ -345,6 +351,19 @@ __global__ __launch_bounds__(kDropThreads) void k_dropout_indices(int N, int n, 
     }
     __syncthreads();
   }
+}
+
+// Per-step schedule values into device memory (include/dpc_render.h, dpc_schedule_update): they arrive as kernel arguments
+struct ScheduleArgs {
+  float xy[DPC_MAX_TAPS], z[DPC_MAX_TAPS];
+  int nxy, nz, n_live;
+};
+__global__ __launch_bounds__(64) void k_schedule_update(ScheduleArgs a, float* __restrict__ dxy, float* __restrict__ dz,
+                                                        int32_t* __restrict__ dn) {
+  const int t = threadIdx.x;
+  if (dxy != nullptr && t < a.nxy) dxy[t] = a.xy[t];
+  if (dz != nullptr && t < a.nz) dz[t] = a.z[t];
+  if (dn != nullptr && t == 0) *dn = a.n_live;
 }
 
 int blocks_for(size_t n) { return (int)std::min<size_t>((n + kThreads - 1) / kThreads, 256 * 8); }
@@ -392,11 +411,32 @@ int dpc_transform_bwd(const DpcParams* p, const float* pc, const float* q, const
   return launch_ok();
 }
 
-int dpc_point_dropout_indices(int B, int N, int n, const int64_t* seed, int32_t* out, void* stream) {
+int dpc_point_dropout_indices_live(int B, int N, int n, const int32_t* n_live, const int64_t* seed, int32_t* out, void* stream) {
   if (B < 0 || N < 0 || n < 0 || n > N) return DPC_ERR_SHAPE;
   if (B == 0 || n == 0) return DPC_OK;
   if (!seed || !out) return DPC_ERR_NULL;
-  hipLaunchKernelGGL(k_dropout_indices, dim3(B), dim3(kDropThreads), 0, (hipStream_t)stream, N, n, seed, out);
+  hipLaunchKernelGGL(k_dropout_indices, dim3(B), dim3(kDropThreads), 0, (hipStream_t)stream, N, n, n_live, seed, out);
+  return launch_ok();
+}
+
+int dpc_point_dropout_indices(int B, int N, int n, const int64_t* seed, int32_t* out, void* stream) {
+  return dpc_point_dropout_indices_live(B, N, n, nullptr, seed, out, stream);
+}
+
+int dpc_schedule_update(const float* host_kern_xy, int taps_xy, const float* host_kern_z, int taps_z, int n_live,
+                        float* dev_taps_xy, float* dev_taps_z, int32_t* dev_n_live, void* stream) {
+  if (taps_xy < 0 || taps_z < 0 || taps_xy > DPC_MAX_TAPS || taps_z > DPC_MAX_TAPS) return DPC_ERR_TAPS;
+  if ((dev_taps_xy && taps_xy > 0 && !host_kern_xy) || (dev_taps_z && taps_z > 0 && !host_kern_z)) return DPC_ERR_NULL;
+  if (!dev_taps_xy && !dev_taps_z && !dev_n_live) return DPC_OK;
+  ScheduleArgs a;
+  a.nxy = dev_taps_xy ? taps_xy : 0;
+  a.nz = dev_taps_z ? taps_z : 0;
+  a.n_live = n_live;
+  for (int i = 0; i < DPC_MAX_TAPS; ++i) {
+    a.xy[i] = i < a.nxy ? host_kern_xy[i] : 0.f;
+    a.z[i] = i < a.nz ? host_kern_z[i] : 0.f;
+  }
+  hipLaunchKernelGGL(k_schedule_update, dim3(1), dim3(64), 0, (hipStream_t)stream, a, dev_taps_xy, dev_taps_z, dev_n_live);
   return launch_ok();
 }
 
@@ -432,19 +472,19 @@ int dpc_smooth(const DpcParams* p, const float* host_kern_xy, const float* host_
   const dim3 g(blocks_for(total)), blk(kThreads);
   // reference order W, H, D (point_cloud_to.py:92-97); the adjoint runs D, H, W with flipped taps
   if (!do_xy) {
-    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, in, out, total, p->D, p->H * p->W, kz);
+    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, in, out, total, p->D, p->H * p->W, kz, p->dev_taps_z, (int)flip);
   } else if (!flip) {
-    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, in, do_z ? out : tmp, total, p->W, 1, kxy);
-    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)(do_z ? out : tmp), do_z ? tmp : out, total, p->H, p->W, kxy);
-    if (do_z) hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)tmp, out, total, p->D, p->H * p->W, kz);
+    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, in, do_z ? out : tmp, total, p->W, 1, kxy, p->dev_taps_xy, (int)flip);
+    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)(do_z ? out : tmp), do_z ? tmp : out, total, p->H, p->W, kxy, p->dev_taps_xy, (int)flip);
+    if (do_z) hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)tmp, out, total, p->D, p->H * p->W, kz, p->dev_taps_z, (int)flip);
   } else {
     const float* src = in;
     if (do_z) {
-      hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, in, out, total, p->D, p->H * p->W, kz);
+      hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, in, out, total, p->D, p->H * p->W, kz, p->dev_taps_z, (int)flip);
       src = out;
     }
-    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, src, tmp, total, p->H, p->W, kxy);
-    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)tmp, out, total, p->W, 1, kxy);
+    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, src, tmp, total, p->H, p->W, kxy, p->dev_taps_xy, (int)flip);
+    hipLaunchKernelGGL(k_conv_axis, g, blk, 0, st, (const float*)tmp, out, total, p->W, 1, kxy, p->dev_taps_xy, (int)flip);
   }
   return launch_ok();
 }

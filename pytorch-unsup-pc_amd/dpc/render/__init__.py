@@ -17,7 +17,8 @@ import numpy as np
 import torch
 
 from . import _native
-from ._ops import Drc, Geometry, ProjectFused, ProjectLossFused, SilhouetteLoss, Smooth, Splat, Transform
+from ._ops import (DeviceSchedule, Drc, Geometry, ProjectFused, ProjectLossFused, SilhouetteLoss, Smooth, Splat, Transform,
+                   status_word, taps_bucket)
 from .predictions import chamfer_of_predictions, load_predictions, save_predictions  # noqa: F401
 
 __all__ = [
@@ -27,6 +28,7 @@ __all__ = [
     "quaternion_rotate", "quaternion_multiply", "quaternion_conjugate", "quaternion_normalise",
     "get_smooth_sigma", "get_dropout_prob", "ProjectionOutputs", "silhouette_loss", "pointcloud_project_loss",
     "point_cloud_distance", "compute_distance", "chamfer_distances", "graphed_project_loss", "prefer_direct_graph_launch", "point_dropout_indices", "save_predictions", "load_predictions", "chamfer_of_predictions",
+    "DeviceSchedule", "check_status", "set_debug_checks", "taps_bucket",
 ]
 
 
@@ -57,13 +59,58 @@ def _check_live_branches(cfg):
                                   "(dpc/util/drc.py:45,84-92)")
 
 
-def _geometry(cfg, kernel=None):
+def _geometry(cfg, kernel=None, schedule=None):
     D, H, W = _grid(cfg)
     kxy = kz = None
     if kernel is not None:
         kxy, kz = _kernel_taps(cfg, kernel)
     return Geometry(D, H, W, kxy, kz, _get(cfg, "camera_distance", 2.0), _get(cfg, "focal_length", 1.875),
-                    _get(cfg, "drc_logsum_clip_val", 1e-5), _get(cfg, "max_depth", 10.0))
+                    _get(cfg, "drc_logsum_clip_val", 1e-5), _get(cfg, "max_depth", 10.0), schedule=schedule)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Bad point indices: an error, never a GPU fault         reference: fancy indexing raises IndexError
+# ------------------------------------------------------------------------------------------------------
+import os as _os
+
+_debug_checks = _os.environ.get("DPC_RENDER_DEBUG", "0") not in ("", "0")
+
+
+def set_debug_checks(on=True):
+    """Debug mode (also DPC_RENDER_DEBUG=1): every call with a `point_index` checks its range on the HOST before anything
+    is launched (one device-to-host synchronisation per call) and raises IndexError like the reference's fancy indexing
+    (dpc/util/point_cloud_to.py:266-295).  Off, the default: the kernels drop an out-of-range entry (it never becomes an
+    address) and flag it in the device status word, which check_status() turns into the same IndexError later."""
+    global _debug_checks
+    _debug_checks = bool(on)
+
+
+def _validate_point_index(point_index, point_cloud):
+    if point_index is None or not _debug_checks or point_index.numel() == 0:
+        return
+    lo, hi = int(point_index.min()), int(point_index.max())
+    n = point_cloud.shape[1]
+    if lo < 0 or hi >= n:
+        raise IndexError("point_index holds %d (valid: 0 .. %d): index out of range for a point set of %d points"
+                         % (lo if lo < 0 else hi, n - 1, n))
+
+
+def check_status(device=None):
+    """Read and clear the device status word (one synchronisation): raises IndexError when a `point_index` entry of any
+    call since the last check was outside its point set -- the reference raises at the call itself; here the kernels dropped
+    the point, flagged it and went on, and the error surfaces where the caller synchronises anyway (reading the loss, a
+    checkpoint).  RuntimeError when a workgroup of an overlapped step gave up waiting (should never happen)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    word = status_word(dev)
+    bits = int(word.item())
+    if bits:
+        word.zero_()
+    if bits & _native.DPC_STATUS_BAD_INDEX:
+        raise IndexError("dpc.render: a point_index entry was out of range for its point set (the point was dropped); "
+                         "set DPC_RENDER_DEBUG=1 to find the call")
+    if bits & _native.DPC_STATUS_WAIT_TIMEOUT:
+        raise RuntimeError("dpc.render: a workgroup of an overlapped step gave up waiting for its producer kernel")
+    return bits
 
 
 def _kernel_taps(cfg, kernel):
@@ -281,7 +328,7 @@ def _outputs_from_grid(cfg, geom, grid_wh, pc, q, t, f, s, point_index):
         if "vox" not in cache:
             vox = grid_wh
             if geom.kz is not None:
-                vox = Smooth.apply(vox, Geometry(geom.D, geom.H, geom.W, None, geom.kz))
+                vox = Smooth.apply(vox, Geometry(geom.D, geom.H, geom.W, None, geom.kz, schedule=geom.schedule))
             if s is not None:
                 vox = torch.clamp(vox * s.reshape(-1, 1, 1, 1).to(vox.dtype), 0.0, 1.0)
             cache["vox"] = vox
@@ -319,7 +366,7 @@ def _project_staged(cfg, geom, pc, q, t, f, s, smooth, point_index=None):
 
 
 def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation, all_rgb, kernel=None,
-                            scaling_factor=None, focal_length=None, smooth=True, point_index=None):
+                            scaling_factor=None, focal_length=None, smooth=True, point_index=None, schedule=None):
     """Project [B,N,3] point clouds to [B,H,W,1] silhouettes (dpc/util/point_cloud_to.py:191-263).
 
     Same positional signature as the reference; returns a dict with the reference's keys
@@ -335,11 +382,18 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation, 
     point_cloud[b // R][point_index[b]] only.  This is pc_point_dropout applied AFTER tf_repeat_0 as the reference does
     (model_pc_to.py:254-258: every replica drops its own points) with neither the replicated [B,N,3] tensor nor the
     gathered [B,n,3] one; the gradient has the shape of `point_cloud` (zeros at points no cloud kept).  Indices from
-    dpc.render.point_dropout_indices (device RNG) or any other source; they may repeat."""
+    dpc.render.point_dropout_indices (device RNG) or any other source; they may repeat.  An entry outside the point set is
+    an IndexError: at once with set_debug_checks() / DPC_RENDER_DEBUG=1, otherwise from check_status() (the kernels drop the
+    point and flag it; nothing out of range is ever read or written).
+
+    `schedule` (a DeviceSchedule): the Gaussian's tap values and the number of live points are read from device memory at
+    run time -- for a call captured in a HIP graph whose sigma / keep-count follow a schedule; `kernel` then only fixes the
+    compiled tap windows (see DeviceSchedule)."""
     if all_rgb is not None:
         raise NotImplementedError("all_rgb: the rgb branch of the reference is dead (point_cloud_to.py:64 AttributeError)")
     _check_live_branches(cfg)
-    geom = _geometry(cfg, kernel if smooth else None)
+    _validate_point_index(point_index, point_cloud)
+    geom = _geometry(cfg, kernel if smooth else None, schedule if smooth else None)
     staged = lambda: _project_staged(cfg, geom, point_cloud, transform, predicted_translation, focal_length,
                                      scaling_factor, smooth, point_index)
     try:
@@ -359,7 +413,8 @@ pointcloud_project = pointcloud_project_fast
 
 
 def pointcloud_project_loss(cfg, point_cloud, transform, predicted_translation, all_rgb, kernel=None,
-                            scaling_factor=None, focal_length=None, gt=None, num_candidates=1, smooth=True, point_index=None):
+                            scaling_factor=None, focal_length=None, gt=None, num_candidates=1, smooth=True, point_index=None,
+                            schedule=None):
     """pointcloud_project_fast followed by the model's projection loss, as ONE autograd node.
 
     What ModelPointCloud does in two steps -- compute_projection (dpc/models/model_pc_to.py:239-282) then
@@ -375,7 +430,8 @@ def pointcloud_project_loss(cfg, point_cloud, transform, predicted_translation, 
     if gt is None:
         raise ValueError("gt (pooled masks [S,H,W,1]) is required")
     _check_live_branches(cfg)
-    geom = _geometry(cfg, kernel if smooth else None)
+    _validate_point_index(point_index, point_cloud)
+    geom = _geometry(cfg, kernel if smooth else None, schedule if smooth else None)
     staged = lambda: _project_staged(cfg, geom, point_cloud, transform, predicted_translation, focal_length,
                                      scaling_factor, smooth, point_index)
     try:
@@ -386,7 +442,7 @@ def pointcloud_project_loss(cfg, point_cloud, transform, predicted_translation, 
         if e.code != _native.DPC_ERR_TAPS:
             raise
         out = pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation, None, kernel, scaling_factor,
-                                      focal_length, smooth, point_index)
+                                      focal_length, smooth, point_index, schedule)
         loss, winner = silhouette_loss(out["proj"], gt, num_candidates)
         return loss, out, winner
     return loss, ProjectionOutputs(proj, staged), winner
@@ -437,7 +493,7 @@ def prefer_direct_graph_launch():
     return os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "0"
 
 
-def point_dropout_indices(num_clouds, num_points, keep_prob, device, generator=None):
+def point_dropout_indices(num_clouds, num_points, keep_prob, device, generator=None, n_live=None):
     """Indices of pc_point_dropout (point_cloud_to.py:269-295) drawn on the device: for each of `num_clouds` clouds,
     int(num_points * keep_prob) DISTINCT point indices, a uniformly random subset (the same distribution as the reference's
     np.random.choice(replace=False), a different random stream), ascending.  int32 [num_clouds, n] for the `point_index`
@@ -447,7 +503,12 @@ def point_dropout_indices(num_clouds, num_points, keep_prob, device, generator=N
     the choice itself is one kernel of this library (dpc_point_dropout_indices: hashed keys + radix select).  No host work,
     no upload, no sync, and safe inside HIP-graph capture: torch advances the generator at every replay, so every replay
     draws anew.  (torch.topk / sort are NOT used here: replayed from a graph they returned out-of-range indices at
-    [128, 8000] on this ROCm build -- tests/test_gpu_parity.py::test_point_dropout_indices_in_a_replayed_graph.)"""
+    [128, 8000] on this ROCm build -- tests/test_gpu_parity.py::test_point_dropout_indices_in_a_replayed_graph.)
+
+    `n_live` (int32 device tensor [1], e.g. DeviceSchedule.n_live): the rows keep their int(num_points * keep_prob) slots
+    (the capacity) but only the first min(n_live, capacity) of each are filled, the count being read on the device -- a
+    captured graph then follows the keep-probability schedule from replay to replay (hand the same tensor to the
+    projection through its DeviceSchedule, which skips the unfilled slots)."""
     N = _native
     device = torch.device(device)
     if device.type != "cuda":
@@ -457,10 +518,12 @@ def point_dropout_indices(num_clouds, num_points, keep_prob, device, generator=N
         raise ValueError("keep_prob %r leaves %d of %d points" % (keep_prob, keep, num_points))
     seed = torch.randint(-2 ** 62, 2 ** 62, (2,), dtype=torch.int64, device=device, generator=generator)
     out = torch.empty((num_clouds, keep), dtype=torch.int32, device=device)
+    if n_live is not None:
+        out.zero_()   # slots beyond the live count are never read by the kernels; zeros keep a debug range check quiet
     with torch.cuda.device(device):
-        rc = N.lib().dpc_point_dropout_indices(int(num_clouds), int(num_points), keep, N.ptr(seed), N.ptr(out),
-                                               N.stream_ptr(device))
-    N.check(rc, "dpc_point_dropout_indices")
+        rc = N.lib().dpc_point_dropout_indices_live(int(num_clouds), int(num_points), keep, N.ptr(n_live), N.ptr(seed),
+                                                    N.ptr(out), N.stream_ptr(device))
+    N.check(rc, "dpc_point_dropout_indices_live")
     return out
 
 

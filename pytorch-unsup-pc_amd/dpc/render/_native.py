@@ -14,20 +14,22 @@ _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__))
 # other implementation to fall back to either way
 LIB_PATH = os.environ.get("DPC_RENDER_LIB") or os.path.join(_CSRC, "libdpc_render.so")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 DPC_MAX_TAPS = 63
 DPC_SMALL_COLS = 12
 COL_DQ, COL_DS, COL_DT, COL_DF = 0, 4, 5, 8
 DPC_ERR_SHAPE = -2
 DPC_ERR_TAPS = -3
 DPC_ERR_LDS = -4
+DPC_STATUS_BAD_INDEX, DPC_STATUS_WAIT_TIMEOUT = 1, 2
 
 # every symbol include/dpc_render.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = (
     "dpc_abi_version", "dpc_strerror", "dpc_mask_words_per_plane", "dpc_cells_bytes", "dpc_workspace_bytes", "dpc_locate",
     "dpc_project_fwd", "dpc_project_bwd", "dpc_project_loss_fwd", "dpc_project_loss_bwd", "dpc_transform_fwd", "dpc_transform_bwd",
     "dpc_splat_fwd", "dpc_splat_bwd", "dpc_smooth", "dpc_drc_fwd", "dpc_drc_bwd",
-    "dpc_silhouette_loss", "dpc_point_dropout_indices", "dpc_nearest_workspace_bytes", "dpc_point_cloud_distance", "dpc_profile_enable", "dpc_profile_disable", "dpc_profile_count", "dpc_profile_get", "dpc_profile_pair_overhead",
+    "dpc_silhouette_loss", "dpc_point_dropout_indices", "dpc_point_dropout_indices_live", "dpc_schedule_update", "dpc_taps_bucket",
+    "dpc_nearest_workspace_bytes", "dpc_point_cloud_distance", "dpc_profile_enable", "dpc_profile_disable", "dpc_profile_count", "dpc_profile_get", "dpc_profile_pair_overhead",
 )
 
 
@@ -36,7 +38,8 @@ class DpcParams(ctypes.Structure):
                 ("W", ctypes.c_int32), ("taps_xy", ctypes.c_int32), ("taps_z", ctypes.c_int32),
                 ("camera_distance", ctypes.c_float), ("focal_length", ctypes.c_float),
                 ("clip_val", ctypes.c_float), ("max_depth", ctypes.c_float), ("point_replicas", ctypes.c_int32),
-                ("N_src", ctypes.c_int32), ("point_index", ctypes.c_void_p)]
+                ("N_src", ctypes.c_int32), ("point_index", ctypes.c_void_p), ("status", ctypes.c_void_p),
+                ("n_live", ctypes.c_void_p), ("dev_taps_xy", ctypes.c_void_p), ("dev_taps_z", ctypes.c_void_p)]
 
 
 class DpcError(RuntimeError):
@@ -99,6 +102,12 @@ def lib():
         L.dpc_smooth.argtypes = [pp, vp, vp, ctypes.c_int, vp, vp, vp, vp]
         L.dpc_point_dropout_indices.restype = ctypes.c_int
         L.dpc_point_dropout_indices.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]
+        L.dpc_point_dropout_indices_live.restype = ctypes.c_int
+        L.dpc_point_dropout_indices_live.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
+        L.dpc_schedule_update.restype = ctypes.c_int
+        L.dpc_schedule_update.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
+        L.dpc_taps_bucket.restype = ctypes.c_int
+        L.dpc_taps_bucket.argtypes = [vp, ctypes.c_int]
         if L.dpc_abi_version() != ABI_VERSION:
             raise RuntimeError("dpc.render: libdpc_render.so ABI %d, expected %d -- rebuild it (make -C %s)"
                                % (L.dpc_abi_version(), ABI_VERSION, _CSRC))

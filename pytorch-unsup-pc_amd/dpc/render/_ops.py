@@ -15,10 +15,13 @@ from . import _native as N
 class Geometry:
     """Per-call constants: grid, camera, tap weights (host side)."""
 
-    __slots__ = ("D", "H", "W", "kxy", "kz", "camera_distance", "focal_length", "clip_val", "max_depth")
+    __slots__ = ("D", "H", "W", "kxy", "kz", "camera_distance", "focal_length", "clip_val", "max_depth", "schedule")
 
     def __init__(self, D, H, W, kxy=None, kz=None, camera_distance=2.0, focal_length=1.875, clip_val=1e-5,
-                 max_depth=10.0):
+                 max_depth=10.0, schedule=None):
+        """schedule: a DeviceSchedule (below) whose device-resident tap values / live-point count the kernels read at run
+        time instead of this object's host arrays -- for captured HIP graphs that follow a sigma / dropout schedule."""
+        self.schedule = schedule
         self.D, self.H, self.W = int(D), int(H), int(W)
         self.kxy = None if kxy is None else np.ascontiguousarray(kxy, dtype=np.float32).reshape(-1)
         self.kz = None if kz is None else np.ascontiguousarray(kz, dtype=np.float32).reshape(-1)
@@ -33,14 +36,94 @@ class Geometry:
     def params(self, B, Npts, point_replicas=1, point_index=None, n_src=0):
         """point_index: int32 device tensor [B,Npts] (kept alive by the caller for the duration of the call) selecting
         every cloud's points out of a stored set of n_src points."""
+        sch = self.schedule
+        dev = None if point_index is None else point_index.device
         return N.DpcParams(int(B), int(Npts), self.D, self.H, self.W,
                            0 if self.kxy is None else self.kxy.size, 0 if self.kz is None else self.kz.size,
                            self.camera_distance, self.focal_length, self.clip_val, self.max_depth, int(point_replicas),
-                           int(n_src), None if point_index is None else point_index.data_ptr())
+                           int(n_src), None if point_index is None else point_index.data_ptr(),
+                           None if dev is None or dev.type != "cuda" else status_word(dev).data_ptr(),
+                           None if sch is None or sch.n_live is None else sch.n_live.data_ptr(),
+                           None if sch is None or self.kxy is None else sch.taps_xy.data_ptr(),
+                           None if sch is None or self.kz is None else sch.taps_z.data_ptr())
 
     def kern_ptrs(self):
         return (None if self.kxy is None else self.kxy.ctypes.data_as(ctypes.c_void_p),
                 None if self.kz is None else self.kz.ctypes.data_as(ctypes.c_void_p))
+
+
+_status = {}
+
+
+def status_word(device):
+    """The int32 status word of `device` that every call with a point_index hands to the kernels (DpcParams.status): the
+    DPC_STATUS_* bits are OR-ed into it on the device; read (and cleared) by dpc.render.check_status at a point where the
+    caller synchronises anyway."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    w = _status.get(device)
+    if w is None:
+        w = _status[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return w
+
+
+class DeviceSchedule:
+    """Per-step schedule values in DEVICE memory, so that a captured HIP graph follows them from replay to replay
+    (dpc/models/model_pc_to.py:59-87, 171-179, 254-258: sigma_rel(step) and the dropout keep-probability are recomputed every
+    step; a graph freezes kernel arguments, not memory).  taps_xy / taps_z hold the Gaussian's current values, n_live the
+    current number of kept points per cloud.  update() is one tiny launch on the current stream (the values travel as its
+    arguments) -- enqueue it in front of a replay.  `buckets` remembers the compiled tap windows the graph was captured
+    for: fits() says whether new values still fit them."""
+
+    def __init__(self, device, kxy, kz, n_live=None, capacity=None):
+        kxy = np.ascontiguousarray(kxy, dtype=np.float32).reshape(-1)
+        kz = np.ascontiguousarray(kz, dtype=np.float32).reshape(-1)
+        self.device = torch.device(device)
+        self.taps_xy = torch.zeros(N.DPC_MAX_TAPS, dtype=torch.float32, device=device)
+        self.taps_z = torch.zeros(N.DPC_MAX_TAPS, dtype=torch.float32, device=device)
+        self.n_live = None if n_live is None else torch.zeros(1, dtype=torch.int32, device=device)
+        self.capacity = capacity
+        self.sizes = (kxy.size, kz.size)
+        self.buckets = (taps_bucket(kxy), taps_bucket(kz))
+        self.update(kxy, kz, n_live)
+
+    def fits(self, kxy, kz, n_live=None):
+        kxy = np.ascontiguousarray(kxy, dtype=np.float32).reshape(-1)
+        kz = np.ascontiguousarray(kz, dtype=np.float32).reshape(-1)
+        if (kxy.size, kz.size) != self.sizes:
+            return False
+        bx, bz = taps_bucket(kxy), taps_bucket(kz)
+        if bx < 0 or bz < 0 or bx > self.buckets[0] or bz > self.buckets[1]:
+            return False
+        return n_live is None or self.capacity is None or n_live <= self.capacity
+
+    def tight(self, kxy, kz, n_live=None):
+        """fits(), and a graph captured for the new values would be no cheaper (same tap windows, capacity not twice the
+        live count)."""
+        if not self.fits(kxy, kz, n_live):
+            return False
+        kxy = np.ascontiguousarray(kxy, dtype=np.float32).reshape(-1)
+        kz = np.ascontiguousarray(kz, dtype=np.float32).reshape(-1)
+        same = (taps_bucket(kxy), taps_bucket(kz)) == self.buckets
+        return same and (n_live is None or self.capacity is None or 2 * n_live > self.capacity or self.capacity <= 512)
+
+    def update(self, kxy, kz, n_live=None):
+        kxy = np.ascontiguousarray(kxy, dtype=np.float32).reshape(-1)
+        kz = np.ascontiguousarray(kz, dtype=np.float32).reshape(-1)
+        if (kxy.size, kz.size) != self.sizes:
+            raise ValueError("the schedule was built for kernels of %s taps, got %s" % (self.sizes, (kxy.size, kz.size)))
+        with torch.cuda.device(self.device):
+            rc = N.lib().dpc_schedule_update(kxy.ctypes.data_as(ctypes.c_void_p), kxy.size, kz.ctypes.data_as(ctypes.c_void_p),
+                                             kz.size, 0 if n_live is None else int(n_live), N.ptr(self.taps_xy),
+                                             N.ptr(self.taps_z), N.ptr(self.n_live), N.stream_ptr(self.device))
+        N.check(rc, "dpc_schedule_update")
+
+
+def taps_bucket(k):
+    """Compiled tap-window radius a 1-D kernel needs in the fused kernels (-1: beyond them)."""
+    k = np.ascontiguousarray(k, dtype=np.float32).reshape(-1)
+    return N.lib().dpc_taps_bucket(k.ctypes.data_as(ctypes.c_void_p), k.size)
 
 
 def _f32(t):

@@ -88,3 +88,57 @@ def test_overlay_next_to_the_reference_itself():
         print('ok')
         """, PKG)
     assert out.strip().endswith("ok")
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/dpc/models"), reason="the reference checkout exists in the build container only")
+def test_the_references_own_caller_through_the_overlay():
+    """north_star: "so dpc/run/train_eval_to.py can import it as a drop-in".  The reference's caller module
+    (dpc/models/model_pc_to.py, import block :15-24) is imported with the overlay in front of the reference's dpc/: the
+    names it binds ARE this build's functions, ModelPointCloud(cfg) constructs from the experiment's yaml, and its own
+    forward (compute_projection, :239-282) reaches dpc.render.pointcloud_project_fast with arguments that bind -- on this
+    GPU-less host that call ends in dpc.render's loud "MI355X only" error, raised after the config, the kernel list and the
+    tensors were accepted (there is no CPU path to fall into)."""
+    out = _run("""
+        import sys
+        sys.path.insert(0, sys.argv[1])            # the line a maintainer adds to dpc/run/startup.py
+        sys.path.append('/root/reference/dpc')     # startup.py's own line (dpc/run/startup.py:4-6)
+        import torch, yaml
+        from models import model_pc_to
+        import dpc.render as R
+        assert model_pc_to.pointcloud_project_fast is R.pointcloud_project_fast
+        assert model_pc_to.smoothing_kernel is R.smoothing_kernel and model_pc_to.pc_point_dropout is R.pc_point_dropout
+        assert model_pc_to.q_mul is R.quaternion_multiply and model_pc_to.q_norm is R.quaternion_normalise
+        assert model_pc_to.q_rotate is R.quaternion_rotate and model_pc_to.q_conj is R.quaternion_conjugate
+        assert model_pc_to.__file__.startswith('/root/reference/dpc/models/')
+
+        class Cfg(dict):
+            __getattr__ = dict.__getitem__
+            __setattr__ = dict.__setitem__
+        cfg = Cfg(yaml.safe_load(open('/root/reference/dpc/resources/default_config.yaml')))
+        cfg.update(yaml.safe_load(open('/root/reference/experiments/chair_unsupervised/config.yaml')))
+        full = model_pc_to.ModelPointCloud(cfg)
+        assert sum(p.numel() for p in full.parameters()) == 61042134      # SURVEY 8(c)
+        del full
+        cfg.update(z_dim=64, fc_dim=64, f_dim=8, pc_num_points=256, vox_size=16, pc_gauss_kernel_size=11, batch_size=2,
+                   step_size=2, input_shape=[32, 32, 3], pc_point_dropout=0.5)
+        model = model_pc_to.ModelPointCloud(cfg)
+        g = torch.Generator().manual_seed(3)
+        images = torch.rand(4, 3, 32, 32, generator=g)
+        inputs = dict(images=images, masks=(torch.rand(4, 1, 32, 32, generator=g) > 0.5).float(), images_1=images[::2])
+        seen = {}
+        real = R._native.require_device
+        def spy(*tensors):
+            seen['tensors'] = [None if t is None else tuple(t.shape) for t in tensors]
+            return real(*tensors)
+        R._ops.N.require_device = spy
+        try:
+            model(inputs, 0, is_training=True, run_projection=True)
+        except RuntimeError as e:
+            assert 'MI355X' in str(e), e
+        else:
+            raise AssertionError('a CPU call went through: there must be no CPU path')
+        # what arrived at the renderer: 2 objects x 2 views x 4 candidates = 16 clouds of 128 kept points, poses, scales
+        assert seen['tensors'][:2] == [(16, 128, 3), (16, 4)] and seen['tensors'][4] == (16, 1), seen
+        print('ok')
+        """, PKG)
+    assert out.strip().endswith("ok")

@@ -698,11 +698,13 @@ def test_point_index_vs_oracle(R, O, K, reps, G, sig):
     close(o2["tr_pc"], ref2["tr_pc"], 2e-6, "point_index: tr_pc of the kept points")
 
 
-@pytest.mark.parametrize("K,reps", [(1, 4), (4, 8), (4, 4), (2, 2)])   # K == reps: one writer per point set (K = reps = 8: the c5 test)
-def test_shared_point_sets_vs_oracle(R, O, K, reps):
+@pytest.mark.parametrize("K,reps,S", [(1, 4, 2), (4, 8, 2), (4, 4, 2), (2, 2, 2), (8, 8, 2), (8, 8, 16)])
+def test_shared_point_sets_vs_oracle(R, O, K, reps, S):
     """Shared point sets without dropout (point_cloud [B/R,N,3], B poses) against the ORACLE on the tf_repeat_0 copies
-    (dpc/models/model_pc_to.py:47-56, 302-306): silhouettes, winners, loss, d(pc) summed over the replicas, d(q), d(s)."""
-    S, N, G = 2, 1300, 32
+    (dpc/models/model_pc_to.py:47-56, 302-306): silhouettes, winners, loss, d(pc) summed over the replicas, d(q), d(s).
+    K == reps: one writer per point set (plain stores in the backward); K = reps = 8, S = 16 is the layout of
+    `bench.py --config c5`."""
+    N, G = 1300, 32
     B = S * reps
     cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
     pc = O.synth_inputs(S, N, G, 5100 + K)[0]
@@ -1301,6 +1303,151 @@ def test_nearest_point_errors(R):
         R.point_cloud_distance(torch.zeros(3, 3), torch.zeros(4, 3))
     p, d, i = R.point_cloud_distance(torch.zeros(0, 3, device="cuda"), torch.zeros(4, 3, device="cuda"))
     assert p.shape == (0, 3) and d.shape == (0,) and i.shape == (0,)
+
+
+# ------------------------------------------------------------------------------------------ round 3: indices, schedules
+def test_bad_point_index_is_an_error_not_a_fault(R, O):
+    """An index row holding N_src and -1 (the reference's fancy indexing raises IndexError for the first, wraps the second,
+    dpc/util/point_cloud_to.py:266-295): nothing out of range is read or written, the entry is dropped, the status word
+    turns it into IndexError at check_status(), the clouds with clean rows are bit-identical to a clean run, and the debug
+    mode raises at the call."""
+    S, reps, Nsrc, n, G, K = 2, 4, 900, 300, 32, 2
+    B = S * reps
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    kern = R.smoothing_kernel(cfg, 0.9)
+    pc = O.synth_inputs(S, Nsrc, G, 8100)[0]
+    _, q, s, _, _, _ = O.synth_inputs(B, 4, G, 8200)
+    gt = O.synth_inputs(B // K, 1, G, 8300)[3]
+    idx = R.point_dropout_indices(B, Nsrc, (n + 0.5) / Nsrc, torch.device("cuda"), torch.Generator(device="cuda").manual_seed(5))
+    assert idx.shape == (B, n)
+    R.check_status()   # clean slate
+
+    def run(index):
+        gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+        loss, out, win = R.pointcloud_project_loss(cfg, gp, gq, None, None, kern, scaling_factor=gs, gt=dev(gt), num_candidates=K,
+                                                   point_index=index)
+        loss.backward()
+        o2 = R.pointcloud_project_fast(cfg, dev(pc), dev(q), None, None, kern, scaling_factor=dev(s), point_index=index)
+        torch.cuda.synchronize()
+        return out["proj"].clone(), gp.grad.clone(), gq.grad.clone(), o2["proj"].clone()
+
+    clean = run(idx)
+    assert R.check_status() == 0
+    bad = idx.clone()
+    bad[3, 7], bad[3, 100], bad[3, 299] = Nsrc, -1, 2 ** 31 - 1    # cloud 3 (point set 0)
+    dirty = run(bad)
+    with pytest.raises(IndexError):
+        R.check_status()
+    assert R.check_status() == 0, "the status word is cleared by the check that raised"
+    others = [b for b in range(B) if b != 3]
+    assert torch.equal(dirty[0][others], clean[0][others]) and torch.equal(dirty[3][others], clean[3][others])
+    assert torch.isfinite(dirty[0]).all() and torch.isfinite(dirty[1]).all() and torch.isfinite(dirty[2]).all()
+    # cloud 3 itself: exactly the projection of its row without the three bad entries
+    keep = torch.ones(n, dtype=torch.bool)
+    keep[[7, 100, 299]] = False
+    sub = pc[0:1].gather(1, idx[3].long().cpu()[keep].view(1, -1, 1).expand(1, -1, 3))
+    want = R.pointcloud_project_fast(cfg, dev(sub), dev(q[3:4]), None, None, kern, scaling_factor=dev(s[3:4]))["proj"]
+    assert torch.equal(dirty[3][3:4], want)
+    R.set_debug_checks(True)
+    try:
+        with pytest.raises(IndexError):
+            R.pointcloud_project_fast(cfg, dev(pc), dev(q), None, None, kern, scaling_factor=dev(s), point_index=bad)
+        R.pointcloud_project_fast(cfg, dev(pc), dev(q), None, None, kern, scaling_factor=dev(s), point_index=idx)
+    finally:
+        R.set_debug_checks(False)
+    assert R.check_status() == 0
+
+
+@pytest.mark.parametrize("K,reps", [(4, 4), (2, 2), (2, 4)])
+def test_repeated_point_indices_vs_oracle(R, O, K, reps):
+    """`point_index` rows may repeat an index (include/dpc_render.h): both contributions are summed into the point's
+    gradient -- also where K == reps, the layout whose single winner per point set otherwise stores plainly."""
+    S, Nsrc, n, G = 3, 500, 260, 32
+    B = S * reps
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    pc = O.synth_inputs(S, Nsrc, G, 8400 + K)[0]
+    _, q, s, _, _, _ = O.synth_inputs(B, 4, G, 8500 + reps)
+    gt = O.synth_inputs(B // K, 1, G, 8600)[3]
+    rows = torch.randint(0, Nsrc, (B, n), generator=torch.Generator().manual_seed(11))   # with replacement: many repeats
+    rows[:, 1] = rows[:, 0]
+    leaf = lambda x: x.clone().requires_grad_(True)
+    cp, cq, cs = leaf(pc), leaf(q), leaf(s)
+    mat = cp.repeat_interleave(reps, dim=0).gather(1, rows.unsqueeze(-1).expand(-1, -1, 3))
+    ref = O.pointcloud_project_fast(cfg, mat, cq, None, None, O.smoothing_kernel(cfg, 0.9), scaling_factor=cs)
+    rloss, rwin = O.proj_loss_pose_candidates(gt, ref["proj"], K)
+    rloss.backward()
+    gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+    loss, out, win = R.pointcloud_project_loss(cfg, gp, gq, None, None, R.smoothing_kernel(cfg, 0.9), scaling_factor=gs, gt=dev(gt),
+                                               num_candidates=K, point_index=rows.int().cuda())
+    loss.backward()
+    assert np.array_equal(win.cpu().numpy(), rwin.numpy())
+    close(out["proj"], ref["proj"], TOL, "repeated indices: proj")
+    close(gp.grad, cp.grad, TOL, "repeated indices: dpc")
+    close(gq.grad, cq.grad, TOL, "repeated indices: dq")
+
+
+def test_device_schedule_follows_sigma_and_keep_count_under_replay(R, O):
+    """A call captured ONCE in a HIP graph, with its Gaussian taps and its live-point count in device memory
+    (DeviceSchedule), replayed while sigma and the keep-count move along their schedules
+    (dpc/models/model_pc_to.py:59-87, 171-179, 254-258): every replay equals the eager call made with that step's kernel and
+    that step's number of points."""
+    S, reps, Nsrc, G, K, cap = 2, 4, 2000, 64, 2, 600
+    B = S * reps
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=21)
+    pc = O.synth_inputs(S, Nsrc, G, 8700)[0]
+    _, q, s, _, _, _ = O.synth_inputs(B, 4, G, 8800)
+    gt = O.synth_inputs(B // K, 1, G, 8900)[3]
+    d = torch.device("cuda")
+    idx = R.point_dropout_indices(B, Nsrc, (cap + 0.5) / Nsrc, d, torch.Generator(device="cuda").manual_seed(6))   # ascending rows
+    assert idx.shape == (B, cap)
+    sig0 = 1.3
+    k0 = R.smoothing_kernel(cfg, sig0)
+    sched = R.DeviceSchedule(d, k0[0], k0[2], n_live=cap, capacity=cap)
+    assert sched.buckets == (R.taps_bucket(k0[0]), R.taps_bucket(k0[2])) and sched.buckets[0] >= 4
+    gp, gq, gs, ggt = dev(pc, True), dev(q, True), dev(s, True), dev(gt)
+
+    def step():
+        gp.grad = gq.grad = gs.grad = None
+        loss, out, _ = R.pointcloud_project_loss(cfg, gp, gq, None, None, k0, scaling_factor=gs, gt=ggt, num_candidates=K,
+                                                 point_index=idx, schedule=sched)
+        loss.backward()
+        return loss, out["proj"]
+
+    side = torch.cuda.Stream(d)
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step()
+        side.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            loss, proj = step()
+        for sig, n in [(1.3, 600), (1.1, 560), (0.9, 301), (0.64, 256), (0.5, 1), (1.3, 600)]:
+            kern = R.smoothing_kernel(cfg, sig)
+            assert sched.fits(kern[0], kern[2], n)
+            sched.update(kern[0], kern[2], n)
+            graph.replay()
+            side.synchronize()
+            got = (loss.clone(), proj.clone(), gp.grad.clone(), gq.grad.clone(), gs.grad.clone())
+            ep, eq, es = dev(pc, True), dev(q, True), dev(s, True)
+            el, eo, _ = R.pointcloud_project_loss(cfg, ep, eq, None, None, kern, scaling_factor=es, gt=ggt, num_candidates=K,
+                                                  point_index=idx[:, :n].contiguous())
+            el.backward()
+            tag = "schedule sigma %.2f n %d: " % (sig, n)
+            close(got[0], el, 1e-6, tag + "loss")
+            close(got[1], eo["proj"], 1e-6, tag + "proj")
+            close(got[2], ep.grad, 2e-6, tag + "dpc")
+            close(got[3], eq.grad, 2e-6, tag + "dq")
+            close(got[4], es.grad, 2e-6, tag + "ds")
+    big = R.smoothing_kernel(cfg, 3.0)
+    assert not sched.fits(big[0], big[2], 100) and not sched.fits(k0[0], k0[2], cap + 1)
+    small = R.smoothing_kernel(cfg, 0.3)
+    assert sched.fits(small[0], small[2], 500) and not sched.tight(small[0], small[2], 500)
+    # the index draw with a device-side count: the first n_live slots of every row are the n_live smallest keys' points
+    sched.update(k0[0], k0[2], 123)
+    gen = lambda: torch.Generator(device="cuda").manual_seed(21)
+    part = R.point_dropout_indices(B, Nsrc, (cap + 0.5) / Nsrc, d, gen(), n_live=sched.n_live)
+    full = R.point_dropout_indices(B, Nsrc, 123.5 / Nsrc, d, gen())
+    assert full.shape == (B, 123) and torch.equal(part[:, :123], full)
 
 
 def test_zz_error_report():
