@@ -17,8 +17,8 @@ import numpy as np
 import torch
 
 from . import _native
-from ._ops import (DeviceSchedule, Drc, Geometry, ProjectFused, ProjectLossFused, SilhouetteLoss, Smooth, Splat, Transform,
-                   status_word, taps_bucket)
+from ._ops import (DeviceSchedule, Drc, Geometry, ProjectFused, ProjectLossFused, ProjectLossStep, SilhouetteLoss, Smooth, Splat,
+                   Transform, status_word, taps_bucket)
 from .predictions import chamfer_of_predictions, load_predictions, save_predictions  # noqa: F401
 
 __all__ = [
@@ -28,7 +28,7 @@ __all__ = [
     "quaternion_rotate", "quaternion_multiply", "quaternion_conjugate", "quaternion_normalise",
     "get_smooth_sigma", "get_dropout_prob", "ProjectionOutputs", "silhouette_loss", "pointcloud_project_loss",
     "point_cloud_distance", "compute_distance", "chamfer_distances", "graphed_project_loss", "prefer_direct_graph_launch", "point_dropout_indices", "save_predictions", "load_predictions", "chamfer_of_predictions",
-    "DeviceSchedule", "check_status", "set_debug_checks", "taps_bucket",
+    "DeviceSchedule", "check_status", "set_debug_checks", "taps_bucket", "project_loss_step",
 ]
 
 
@@ -446,6 +446,15 @@ def pointcloud_project_loss(cfg, point_cloud, transform, predicted_translation, 
         loss, winner = silhouette_loss(out["proj"], gt, num_candidates)
         return loss, out, winner
     return loss, ProjectionOutputs(proj, staged), winner
+
+
+def project_loss_step(cfg, kernel, num_clouds, num_points, device, overlap=True, schedule=None):
+    """A ProjectLossStep plan for pointcloud_project_loss + backward at fixed shapes (one pose candidate per sample): static
+    buffers, one native call per step, the kernels of a step overlapped on two HIP streams with per-cloud hand-offs
+    (`overlap=False`: the plain sequence).  See dpc.render._ops.ProjectLossStep; reference call sequence:
+    compute_projection + add_proj_loss + loss.backward() (dpc/models/model_pc_to.py:239-282, 339-385; dpc/run/train_to.py:122)."""
+    _check_live_branches(cfg)
+    return ProjectLossStep(_geometry(cfg, kernel, schedule), num_clouds, num_points, device, overlap)
 
 
 def graphed_project_loss(cfg, kernel, point_cloud, transform, scaling_factor, gt, num_candidates=1):

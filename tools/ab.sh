@@ -2,8 +2,8 @@
 # A/B of library variants on the GPU box: tools/ab.sh <out-name> <bench args...> -- <variant> [<variant> ...]
 # variant = "main" (in-tree library) or a scratch/<name> build; each runs bench.py twice, interleaved.
 set -o pipefail
-cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r02
-out=gpurun_out/r02/$1; shift
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r03
+out=gpurun_out/r03/$1; shift
 args=(); while [ "$1" != "--" ]; do args+=("$1"); shift; done; shift
 : > $out
 for rnd in 1 2; do
