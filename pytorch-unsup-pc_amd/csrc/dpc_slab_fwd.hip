@@ -28,7 +28,10 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
   extern __shared__ __attribute__((aligned(16))) unsigned int member[];   // (D + 1) x 8 words, sized by the launch
   const Blk bk = block_coords(P.B);
   const int b = bk.y, blk = bk.x, tid = threadIdx.x;
-  if (HO && blockIdx.x == 0 && tid == 0)   // this run has begun: the side stream's gate lets the slab kernel through
+  // the LAST workgroup of this run has begun, so every workgroup of the grid is resident or done (dispatch is in block
+  // order): the side stream's gate lets the slab kernel through -- any earlier and its 141 KB workgroups would take the CUs
+  // from the chunks that are still waiting for one (measured: k_locate 9 -> 16 us)
+  if (HO && blockIdx.x == gridDim.x - 1 && tid == 0)
     __hip_atomic_store(ho.started, ho.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int D = P.D, nbins = D + 1;
   const int i = blk * kLocThreads + tid;

@@ -1450,7 +1450,7 @@ def test_device_schedule_follows_sigma_and_keep_count_under_replay(R, O):
     assert full.shape == (B, 123) and torch.equal(part[:, :123], full)
 
 
-@pytest.mark.parametrize("B,N,sig", [(8, 3000, 0.64), (32, 8000, 0.64), (5, 700, 1.3)])
+@pytest.mark.parametrize("B,N,sig", [(8, 3000, 0.64), (32, 8000, 0.64), (5, 700, 1.0)])
 def test_overlapped_step_is_bit_identical_to_the_plain_sequence(R, O, B, N, sig):
     """dpc_project_loss_step: the four kernels of a step overlapped on two HIP streams, the dependencies carried by
     per-cloud counters in memory (write-through stores, bounded polls).  Against the same plan run as the plain launch

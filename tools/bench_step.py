@@ -37,6 +37,9 @@ for name, ov in (("plan, plain sequence", False), ("plan, overlapped", True)):
     print("%-24s %.2f us per step (%.0f clouds/s), host %.1f us per call, overlapped=%d, loss %.6f"
           % (name, us, B / us * 1e6, host, plan.overlapped.value, float(plan.loss)))
     res[name] = [x.clone() for x in (plan.loss, plan.proj, plan.dpc, plan.dq, plan.ds)]
+    from dpc.render import _native
+    prof = _native.profile_kernels(lambda: [plan.run(pc, q, s, gt) for _ in range(30)], d)
+    print("    per-kernel event times (us):", {k: round(1e3 * sum(v[10:]) / len(v[10:]), 2) for k, v in prof.items()})
     plan.close()
 print("bit-identical:", all(torch.equal(a, b) for a, b in zip(res["plan, plain sequence"], res["plan, overlapped"])))
 print("status word:", R.check_status())
