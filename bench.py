@@ -35,11 +35,13 @@ for p in (ROOT, os.path.join(ROOT, "pytorch-unsup-pc_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# HIP-graph replay without the runtime's pre-built AQL packets ("graph packet capture", on by default in ROCm 7): with it
-# every kernel boundary inside a replayed graph costs about 1 us more on MI355X (c2: 61.2 -> 57.2 us per step, the same
-# kernels).  A runtime setting read when HIP initialises, so it is set before torch is imported;
-# an explicit value in the environment wins (DEBUG_CLR_GRAPH_PACKET_CAPTURE=1 python bench.py ... measures the default).
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # = dpc.render.prefer_direct_graph_launch()
+# The default step is ONE native call that enqueues the four kernels (dpc_project_loss_step): no HIP graph, no runtime
+# setting involved.  Only `--launch graph` (the round-1/2 way: the autograd path captured and replayed) asks for graph replay
+# without the runtime's pre-built AQL packets ("graph packet capture", the default of ROCm 7, costs about 1 us per kernel
+# boundary inside a replayed graph on MI355X): read when HIP initialises, so set before torch is
+# imported; an explicit DEBUG_CLR_GRAPH_PACKET_CAPTURE in the environment wins.
+if "graph" in [a for i, a in enumerate(sys.argv) if i and sys.argv[i - 1] == "--launch"] or "--launch=graph" in sys.argv:
+    os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # = dpc.render.prefer_direct_graph_launch()
 
 import torch
 import torch.distributed as dist
@@ -82,24 +84,45 @@ def step_bytes_per_cloud(n, g, k_cand):
     return fwd + bwd / k_cand
 
 
-PROFILE_SUMMARIES = ("r02_rocprof_summary.json", "r02_rocprof_summary_c4.json", "r01_rocprof_summary.json")   # newest first
+PROFILE_SUMMARIES = ("r03_rocprof_summary.json", "r03_rocprof_summary_c4.json", "r02_rocprof_summary.json",
+                     "r02_rocprof_summary_c4.json", "r01_rocprof_summary.json")   # newest first
 
 
-def measured_traffic(kernel, config="c2"):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary of THIS config (FETCH_SIZE / WRITE_SIZE
-    collected in separate passes by tools/profile_gpu.sh and corrected with the calibration kernels, as
-    MI355X_MICROARCH.md prescribes); None when no profile of this kernel at this config is on file."""
+def profile_summary(config="c2"):
+    """The newest committed rocprofv3 summary of THIS config (tools/profile_gpu.sh: kernel trace + FETCH_SIZE / WRITE_SIZE
+    in separate passes, corrected with the calibration kernels as MI355X_MICROARCH.md prescribes), or None."""
     for name in PROFILE_SUMMARIES:
         try:
             summary = json.load(open(os.path.join(ROOT, "profiles", name)))
         except (OSError, ValueError):
             continue
-        if summary.get("config", "c2") != config:
-            continue
-        for kname, rec in summary.get("kernels", {}).items():
-            if kname.split("<")[0] == kernel and rec.get("hbm_bytes_per_launch"):
-                return rec["hbm_bytes_per_launch"]
+        if summary.get("config", "c2") == config:
+            summary["file"] = "profiles/" + name
+            return summary
     return None
+
+
+def measured_traffic(kernel, config="c2"):
+    """HBM bytes per launch of `kernel` from that summary; None when no profile of this kernel at this config is on file."""
+    summary = profile_summary(config)
+    for kname, rec in (summary or {}).get("kernels", {}).items():
+        if kname.split("<")[0] == kernel and rec.get("hbm_bytes_per_launch"):
+            return rec["hbm_bytes_per_launch"]
+    return None
+
+
+def dominant_kernel(kern_ms, config="c2"):
+    """The kernel the `roofline` object describes.  Two kernels of the step are within a microsecond of each other and swap
+    places from run to run, so the choice is made ONCE per profile: the kernel with the largest average duration in the
+    committed rocprofv3 summary of this config (when it is among the kernels this run launched), else the longest of this
+    run's own event timings."""
+    summary = profile_summary(config)
+    if summary:
+        ranked = sorted(summary.get("kernels", {}).items(), key=lambda kv: kv[1].get("avg_us", 0.0), reverse=True)
+        for kname, _ in ranked:
+            if kname.split("<")[0] in kern_ms:
+                return kname.split("<")[0], summary["file"]
+    return (max(kern_ms, key=kern_ms.get), "this run's event timings") if kern_ms else (None, None)
 
 
 def synthetic_inputs(b, n, g, seed):
@@ -290,6 +313,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of HIP graph replay")
+    ap.add_argument("--launch", choices=["plan", "graph"], default="plan",
+                    help="plan (default, one pose candidate per sample): one native call per step enqueues the four kernels "
+                         "(dpc.render.project_loss_step); graph: the autograd path captured into a HIP graph and replayed")
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--split", type=int, default=1,
@@ -416,6 +442,17 @@ def main():
 
         last = [static_loss if graph is not None else None]
 
+        # the default step: forward + backward as ONE native call on static buffers (no graph, no Python between launches)
+        plan = None
+        if (args.launch == "plan" and K_CAND == 1 and ns == 1 and args.api == "fused" and not args.no_graph
+                and args.in_flight == 1 and args.split == 1):
+            plan = R.project_loss_step(cfg, kern, B, N_PTS, device)
+            plan.bind(pc.detach(), q.detach(), s.detach(), gt)
+            for _ in range(3):
+                plan.run()
+            side.synchronize()
+            last[0] = plan.loss
+
         # --in-flight n > 1: n - 1 more lanes, each with its own inputs, gradients, workspace pool, graph and stream
         def new_lane():
             """One more independent batch: its own inputs, gradients, buffers, HIP graph and stream."""
@@ -476,7 +513,9 @@ def main():
                 for lg, lst in parts:
                     side.wait_stream(lst)      # join
                 return
-            if lanes and i % args.in_flight:
+            if plan is not None:
+                plan.run()
+            elif lanes and i % args.in_flight:
                 lg, lst = lanes[i % args.in_flight - 1]
                 with torch.cuda.stream(lst):
                     lg.replay()
@@ -515,7 +554,7 @@ def main():
         # per-kernel durations (eager pass, library's event profiler) -> dominant kernel
         kern_ms = {}
         if rank == 0:
-            prof = _native.profile_kernels(lambda: [step() for _ in range(30)], device)
+            prof = _native.profile_kernels(lambda: [(plan.run() if plan is not None else step()) for _ in range(30)], device)
             # An empty event pair executes two markers back to back; a bracketed kernel exposes one of them, so
             # half the empty-pair reading is subtracted (reproduces rocprofv3's kernel durations to ~0.3 us here).
             floor_ms = 0.5 * _native.event_pair_overhead_ms(device)
@@ -533,8 +572,13 @@ def main():
                 b_.record(side)
                 b_.synchronize()
                 return 1e3 * a.elapsed_time(b_) / n
-            wins = sorted(window_us(graph.replay, 20) for _ in range(15))
-            extras["step_us"] = {"median": wins[len(wins) // 2], "best": wins[0], "windows": "15 x 20 replays"}
+            wins = sorted(window_us(plan.run if plan is not None else graph.replay, 20) for _ in range(15))
+            extras["step_us"] = {"median": wins[len(wins) // 2], "best": wins[0], "windows": "15 x 20 steps"}
+            if plan is not None:   # the same kernels as a replayed HIP graph of the autograd path (rounds 1-2), for comparison
+                gw = sorted(window_us(graph.replay, 20) for _ in range(15))
+                extras["hip_graph_replay"] = {"median_us": gw[len(gw) // 2], "best_us": gw[0], "point_clouds_per_sec": B / (gw[len(gw) // 2] * 1e-6),
+                                              "packet_capture": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0",
+                                              "note": "autograd path captured once and replayed; not the value of this line"}
             if args.api == "fused" and ns == 1 and not lanes and not parts:
                 # NOT the contract's number: two INDEPENDENT batches in flight (second graph, second stream, no join between
                 # steps) -- how much of the one-chain step is latency and kernel tails that a second chain fills
@@ -575,7 +619,7 @@ def main():
     ms_per_step = 1e3 * wall / args.steps
     a_bytes = step_bytes_per_cloud(N_PTS, G, K_CAND)   # = A(N,G) of SURVEY 8(d) when every cloud runs its backward
     kb = kernel_bytes_per_cloud(N_PTS, G)
-    dom = max(kern_ms, key=kern_ms.get) if kern_ms else None
+    dom, dom_from = dominant_kernel({k: v for k, v in kern_ms.items() if k in kb}, args.config)
     # clouds a launch really works on: the backward kernels skip the losing pose candidates
     live = {k: (B // K_CAND if k in ("k_zcol_bwd", "k_gather_hw") else B) for k in kb}
     roofline = None
@@ -583,8 +627,15 @@ def main():
         ach = live[dom] * kb[dom] / (kern_ms[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": ach / HBM_PEAK_GBS, "traffic": measured_traffic(dom, args.config), "avg_launch_us": 1e3 * kern_ms[dom],
-                    "algorithmic_bytes_per_launch": live[dom] * kb[dom]}
+                    "algorithmic_bytes_per_launch": live[dom] * kb[dom], "chosen_by": dom_from,
+                    # every kernel of the step the same way (the two slab kernels are level and used to swap places here)
+                    "all_kernels": {k: {"frac": live[k] * kb[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_us": 1e3 * v,
+                                        "algorithmic_bytes_per_launch": live[k] * kb[k], "traffic": measured_traffic(k, args.config)}
+                                    for k, v in sorted(kern_ms.items()) if k in kb}}
     step_ach = (B * a_bytes) / (dev_ms * 1e-3 / args.steps) / 1e9
+    # what the step's launches really move (sum of the committed PMC figures) against the same step time
+    own = [measured_traffic(k, args.config) for k in kern_ms if k in kb]
+    own_bytes = sum(own) if own and all(x is not None for x in own) else None
     out = {
         "metric": "point-clouds/sec (8000 pts->64^3->128^2 proj) fwd+bwd", "value": clouds_per_s,
         "unit": "point-clouds/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -596,13 +647,17 @@ def main():
                                   2 * G, 2 * G, "loss sum((proj-gt)^2)/B" if K_CAND == 1 else
                                   "min-of-%d pose-candidate loss" % K_CAND),
                    "clouds_per_gpu": B, "points": N_PTS, "grid": G, "taps": KSIZE, "sigma_rel": SIGMA_REL,
-                   "launch": "eager" if graph is None else "hip-graph replay", "streams": ns, "batches_in_flight": args.in_flight, "split": args.split,
-                   "hip_graph_packet_capture": os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0", "api": args.api,
+                   "launch": "one native call per step (dpc_project_loss_step), no HIP graph" if plan is not None else
+                             ("eager" if graph is None else "hip-graph replay"), "streams": ns, "batches_in_flight": args.in_flight, "split": args.split,
+                   "hip_graph_packet_capture": None if plan is not None else os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0",
+                   "api": args.api,
                    "sharding": "clouds, no collective"},
         "roofline": roofline,
         "roofline_step": {"bound": "hbm", "achieved": step_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": step_ach / HBM_PEAK_GBS, "algorithmic_bytes_per_cloud": a_bytes,
                           "device_ms_per_step": dev_ms / args.steps,
+                          "own_traffic_bytes_per_step": own_bytes,
+                          "own_traffic_frac": None if own_bytes is None else own_bytes / (dev_ms * 1e-3 / args.steps) / 1e9 / HBM_PEAK_GBS,
                           "note": "whole fwd+bwd step on rank 0 (HIP events on the launch stream) priced with A(N,G) of SURVEY 8(d)"
                                   + ("" if K_CAND == 1 else "; losing pose candidates run no backward, their backward bytes are not counted")},
         "kernels_us": {k: 1e3 * v for k, v in sorted(kern_ms.items())},

@@ -48,9 +48,8 @@ enum {
 
 /* Bits of the optional device status word (DpcParams.status). */
 enum {
-  DPC_STATUS_BAD_INDEX = 1,   /* a point_index entry was outside [0, N_src): the point was dropped (the reference's fancy
+  DPC_STATUS_BAD_INDEX = 1    /* a point_index entry was outside [0, N_src): the point was dropped (the reference's fancy
                                * indexing raises IndexError there, dpc/util/point_cloud_to.py:266-295)                   */
-  DPC_STATUS_WAIT_TIMEOUT = 2 /* overlapped step (dpc_step_*): a workgroup gave up waiting for the kernel in front of it  */
 };
 
 /* Geometry and camera constants of one call (dpc/resources/default_config.yaml:77-89 and the cfg fields
@@ -191,32 +190,18 @@ int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, co
                          int column_backward_done, float* dpc, float* dsmall, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
- * The whole step -- dpc_project_loss_fwd (one pose candidate per sample, column backward fused) followed by
- * dpc_project_loss_bwd -- as ONE call that lets its kernels overlap.  Launched back to back in one stream, the four kernels
- * put the whole chip through one phase at a time, although a cloud's kernels depend on that cloud's data only (the
- * renderer has no cross-cloud term).  Here the forward slab kernel runs on a second HIP stream owned by
- * `state`, and per-cloud counters in `handoff` carry the dependencies k_locate -> slab kernel -> ray-march kernel through
- * memory (write-through stores, a bounded poll): a cloud's ray march starts when that cloud's slabs are stored, while the
- * slab kernel is still at work on later clouds.  Results are bit-identical to the two separate calls.
- *   state    from dpc_step_state_create (one private non-blocking stream; one state per concurrently running step; not
- *            thread-safe); NULL = the plain sequence on `stream`
- *   handoff  dpc_step_handoff_bytes(p) bytes of device memory, ZEROED ONCE by the caller before the first call, then left
- *            to the library (counters that only grow); tied to `state`
- *   fwd_dsmall, dsmall, workspace, dloss: as bwd_dsmall / dsmall / workspace / dloss of the two calls above
- *   *overlapped (host, may be NULL) = 1 when the overlapped schedule ran, 0 when the configuration fell back to the plain
- *            sequence (anything but 64^3 grids with a Gaussian of effective radius 1..6, N <= 16384, B <= 32)
- * Everything is enqueued; nothing synchronises.  On return of the LAST kernel on `stream` all outputs are complete, so the
- * caller's stream order is all it needs.  DPC_STATUS_WAIT_TIMEOUT in p->status: a poll gave up after 2 s (never seen).
+ * The whole step in ONE call: dpc_project_loss_fwd (one pose candidate per sample, column backward fused into the forward)
+ * followed by dpc_project_loss_bwd -- four launches enqueued back to back by native code.  What a training loop calls once
+ * per step instead of replaying a captured HIP graph of the two calls: the same kernels, the same results bit for bit, and
+ * no graph (on MI355X / ROCm 7.2 the eager native sequence is 2-3 us per step FASTER than the replayed graph: 55.3 against
+ * 57.2-58.2 us at B = 32, N = 8000, 64^3; host cost of the call 18 us, well under the GPU time).
+ *   fwd_dsmall, dsmall, workspace, dloss: as bwd_dsmall / dsmall / workspace / dloss of the two calls above.
+ * DPC_ERR_UNSUPPORTED when the column backward cannot be fused (see dpc_project_loss_fwd): use the two calls then.
  * ------------------------------------------------------------------------------------------------- */
-typedef struct DpcStepState DpcStepState;
-int dpc_step_state_create(DpcStepState** out);
-int dpc_step_state_destroy(DpcStepState* state); /* waits for the private stream to drain */
-size_t dpc_step_handoff_bytes(const DpcParams* p);
-int dpc_project_loss_step(DpcStepState* state, const DpcParams* p, const float* pc, const float* q, const float* t,
-                          const float* f, const float* s, const float* host_kern_xy, const float* host_kern_z,
-                          const float* gt, void* cells, float* grid_wh, uint64_t* mask, float* proj, float* sse, float* loss,
-                          int32_t* winner, void* workspace, float* fwd_dsmall, const float* dloss, float* dpc, float* dsmall,
-                          void* handoff, int* overlapped, void* stream);
+int dpc_project_loss_step(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                          const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt, void* cells,
+                          float* grid_wh, uint64_t* mask, float* proj, float* sse, float* loss, int32_t* winner,
+                          void* workspace, float* fwd_dsmall, const float* dloss, float* dpc, float* dsmall, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Stage-level entry points (one per reference function), used for the sub-stage API and to cross-check the

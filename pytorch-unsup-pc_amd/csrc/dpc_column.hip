@@ -130,14 +130,12 @@ __global__ __launch_bounds__(kColThreads, (DD <= 64 ? 4 : 2)) void k_zcol_fwd(Dp
 #ifndef DPC_ZFB_2WAVE_MAX
 #define DPC_ZFB_2WAVE_MAX 128  // deepest column that is compiled for two waves per SIMD (256 VGPRs per lane)
 #endif
-// HO: overlapped step (dpc_kernels.h, Handoff) -- the forward slab kernel runs on another stream at the same time; the
-// workgroup waits until all slabs of its cloud are published and reads T with sc1 loads.
-template <int DD, int RB, int RPL, bool HO>
+template <int DD, int RB, int RPL>
 __global__ __launch_bounds__(kColThreads, (RPL * DD <= DPC_ZFB_2WAVE_MAX ? 2 : 1))
 void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, const float* __restrict__ s, TapsT<RB> taps_arg,
                    TapsT<RB> taps_adj_arg, float* __restrict__ proj, float* __restrict__ dT, float* __restrict__ ds_part,
                    int n_ds_part, unsigned long long* __restrict__ tickets, SseFormat cf, SseFormat bf, float* __restrict__ dsmall,
-                   unsigned int* __restrict__ cg_count, LossArgs la, Handoff ho) {
+                   unsigned int* __restrict__ cg_count, LossArgs la) {
   typedef float vec __attribute__((ext_vector_type(RPL)));
   const TapsT<RB> taps = resolve_taps<RB>(taps_arg, P.dev_taps_z, P.taps_z, false);
   const TapsT<RB> taps_adj = resolve_taps<RB>(taps_adj_arg, P.dev_taps_z, P.taps_z, true);
@@ -145,7 +143,6 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
   const Blk bk = block_coords(P.B);
   const int b = bk.y, ray = RPL * (bk.x * kColThreads + threadIdx.x);
   const bool live = ray < HW;
-  if constexpr (HO) handoff_wait(ho.splatted + b, ho.epoch * ho.slabs, ho.status);
   const RayConst rc = ray_const(rh, s, b);
   float sq = 0.f, ds_acc = 0.f;
   float y[DD][RPL], g[RPL], gT[RPL];
@@ -158,9 +155,8 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
     if constexpr (RPL == 1) {
       const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Tbuf + (size_t)b * DD * HW), 0, DD * HW * 4, 0x00020000);
 #pragma unroll
-      for (int z = 0; z < DD; ++z) c[z][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src, ray * 4, z * HW * 4, HO ? kSc1 : 0));
+      for (int z = 0; z < DD; ++z) c[z][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(src, ray * 4, z * HW * 4, 0));
     } else {
-      static_assert(!HO || RPL == 1, "the hand-off variant reads one ray per lane");
 #pragma unroll
       for (int z = 0; z < DD; ++z) {
         const vec v = *reinterpret_cast<const vec*>(col + (size_t)z * HW);
@@ -522,45 +518,21 @@ __global__ __launch_bounds__(kColThreads) void k_zcol_bwd_dyn(DpcParams P, RayHo
 
 }  // namespace
 
-// the hand-off variant is compiled for the configurations the overlapped step covers: 64-deep columns, the radius
-// buckets of the x-in-lanes slab kernel
-bool zcol_handoff_applies(const DpcParams* p, const TapPlan& pz) {
-  return DPC_ZFB_RPL == 1 && p->D == 64 && (pz.bucket == 1 || pz.bucket == 2 || pz.bucket == 3 || pz.bucket == 4 || pz.bucket == 6);
-}
-
 int launch_zcol_fwdbwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* Tbuf, const float* s,
                        float* proj, float* dT, float* ds_part, int ntile, unsigned long long* tickets, float* bwd_dsmall,
-                       unsigned int* cg_count, const LossArgs& la, hipStream_t st, const Handoff* ho) {
+                       unsigned int* cg_count, const LossArgs& la, hipStream_t st) {
   int rc = DPC_OK;
   const RayHost rh = ray_host(p);
   constexpr int kRpl = DPC_ZFB_RPL;
   dim3 gpair(((p->H * p->W / kRpl + kColThreads - 1) / kColThreads) * p->B);
   // field layouts of the per-cloud words (contributors: ray tiles) and of the batch word (contributors: clouds)
   const SseFormat cf = sse_format(gpair.x / p->B, kTileSseCap), bf = sse_format(p->B, (double)kTileSseCap * (gpair.x / p->B));
-  const Handoff none{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
-  if (ho != nullptr) {
-    if (!zcol_handoff_applies(p, pz)) return DPC_ERR_UNSUPPORTED;
-#define DPC_ZFB_HO(RB)                                                                                             \
-  {                                                                                                                \
-    const TapsT<RB> tzf = make_taps<RB>(host_kern_z, pz, false), tza = make_taps<RB>(host_kern_z, pz, true);       \
-    DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<64, RB, 1, true>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, cf, bf, bwd_dsmall, cg_count, la, *ho); \
-  }
-    switch (pz.bucket) {
-      case 1: DPC_ZFB_HO(1); break;
-      case 2: DPC_ZFB_HO(2); break;
-      case 3: DPC_ZFB_HO(3); break;
-      case 4: DPC_ZFB_HO(4); break;
-      case 6: DPC_ZFB_HO(6); break;
-    }
-#undef DPC_ZFB_HO
-    return launch_ok();
-  }
 #define DPC_ZFB(RB)                                                                                                \
   {                                                                                                                \
     const TapsT<RB> tzf = make_taps<RB>(host_kern_z, pz, false), tza = make_taps<RB>(host_kern_z, pz, true);       \
-    if (p->D == 32) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<32, RB, kRpl, false>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, cf, bf, bwd_dsmall, cg_count, la, none); \
-    else if (p->D == 64) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<64, RB, kRpl, false>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, cf, bf, bwd_dsmall, cg_count, la, none); \
-    else DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<128, RB, kRpl, false>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, cf, bf, bwd_dsmall, cg_count, la, none); \
+    if (p->D == 32) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<32, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, cf, bf, bwd_dsmall, cg_count, la); \
+    else if (p->D == 64) DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<64, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, cf, bf, bwd_dsmall, cg_count, la); \
+    else DPC_LAUNCH("k_zcol_fwdbwd", (k_zcol_fwdbwd<128, RB, kRpl>), gpair, dim3(kColThreads), 0, st, *p, rh, Tbuf, s, tzf, tza, proj, dT, ds_part, ntile, tickets, cf, bf, bwd_dsmall, cg_count, la); \
   }
   DPC_FOR_BUCKET(pz.bucket, DPC_ZFB)
 #undef DPC_ZFB

@@ -66,34 +66,10 @@ bool can_fuse_column_backward(const DpcParams* p, const TapPlan& pz, int K, cons
          aligned8(grid_wh) && aligned8(proj) && aligned8(gt) && aligned8(workspace);
 }
 
-}  // namespace
-
-// State of the overlapped step (include/dpc_render.h): the private stream of the forward slab kernel and the run counter
-struct DpcStepState {
-  hipStream_t side;
-  unsigned int epoch;
-};
-
-namespace {
-
-// counters of the overlapped step inside the caller's `handoff` buffer: located[B], splatted[B], started[1]
-size_t handoff_bytes(const DpcParams* p) { return ws_round(((size_t)2 * p->B + 1) * sizeof(unsigned int)); }
-
-// Can this call run the overlapped schedule?  The hand-off variants exist for the x-in-lanes slab kernel (64^3, radius
-// bucket 1..6); 32-bit offsets into the record store; the flat record table; and the spinning ray-march workgroups must all
-// be resident next to the slab kernel's without ever filling the chip (at most two per CU).
-bool can_overlap(const DpcParams* p, const TapPlan& pxy, const TapPlan& pz) {
-  return p->N > 0 && xl_applies(p, pxy.bucket) && zcol_handoff_applies(p, pz) && p->D % xl_planes_per_slab() == 0 &&
-         num_chunks(p->N) <= DPC_WAVE &&
-         (size_t)p->B * num_chunks(p->N) * chunk_bytes(p->D) < 0x7fffffffull &&
-         (size_t)p->B * col_tiles(p) <= (size_t)2 * kNumCUs;
-}
-
 int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f, const float* s,
                      const float* host_kern_xy, const float* host_kern_z, float* tr_pc, void* cells, float* raw,
                      float* grid_wh, float* smoothed, uint64_t* mask, float* proj, float* trans, const LossArgs& la,
-                     void* bwd_workspace, float* bwd_dsmall, hipStream_t st, DpcStepState* step = nullptr,
-                     void* handoff = nullptr, int* overlapped = nullptr) {
+                     void* bwd_workspace, float* bwd_dsmall, hipStream_t st) {
   int rc = validate(p);
   if (rc != DPC_OK) return rc;
   if (p->B == 0) return DPC_OK;  // no clouds (an empty shard): every array is empty, its pointer may be NULL
@@ -103,26 +79,8 @@ int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const 
   const TapPlan pxy = plan_taps(host_kern_xy, p->taps_xy), pz = plan_taps(host_kern_z, p->taps_z);
   if (pxy.bucket < 0) return DPC_ERR_TAPS;  // in-LDS passes need a radius bucket; caller composes the stage ops
   float* Tbuf = grid_wh;
-  const Cells cv = cells_view(p, cells);
-  if (overlapped) *overlapped = 0;
-  if (step != nullptr && handoff != nullptr && bwd_workspace != nullptr && bwd_dsmall != nullptr && la.loss_direct != nullptr &&
-      raw == nullptr && tr_pc == nullptr && can_overlap(p, pxy, pz) &&
-      can_fuse_column_backward(p, pz, la.K, Tbuf, proj, la.gt, bwd_workspace)) {
-    // the overlapped schedule: k_locate and the ray march on the caller's stream, the slab kernel (behind its gate) on the
-    // private one; the dependencies are the per-cloud counters in `handoff`
-    unsigned int* words = static_cast<unsigned int*>(handoff);
-    Handoff ho{words, words + p->B, words + 2 * (size_t)p->B, p->status, ++step->epoch, (unsigned int)xl_slabs_per_cloud(p)};
-    const Workspace w = workspace_view(p, bwd_workspace);
-    if ((rc = launch_locate(p, 0, pc, q, t, f, nullptr, cells, st, &ho)) != DPC_OK) return rc;
-    if ((rc = launch_gate(ho, step->side)) != DPC_OK) return rc;
-    if ((rc = launch_splat_xl(pxy.bucket, p, cv, host_kern_xy, pxy, Tbuf, mask, la.sse, la.loss_direct, la.winner_out, w.tickets,
-                              step->side, &ho)) != DPC_OK) return rc;
-    if (overlapped) *overlapped = 1;
-    return launch_zcol_fwdbwd(p, host_kern_z, pz, Tbuf, s, proj, w.dT, w.ds_part, col_tiles(p), w.tickets, bwd_dsmall, w.cg_count,
-                              la, st, &ho);
-  }
-
   if ((rc = launch_locate(p, 0, pc, q, t, f, tr_pc, cells, st)) != DPC_OK) return rc;
+  const Cells cv = cells_view(p, cells);
   // fused loss with one candidate per sample and a backward workspace: the ray-march kernel also runs the column
   // backward; its per-cloud sum-and-count words live behind the ds partials and are zeroed by the slab kernel
   const bool fuse_bwd = bwd_workspace != nullptr && bwd_dsmall != nullptr && la.loss_direct != nullptr &&
@@ -210,42 +168,19 @@ int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, co
   return launch_loss_finalize(sse_tiles, col_tiles(p), sse, S, num_candidates, la.inv_S, loss, winner, (hipStream_t)stream);
 }
 
-int dpc_step_state_create(DpcStepState** out) {
-  if (!out) return DPC_ERR_NULL;
-  DpcStepState* st = new DpcStepState{nullptr, 0u};
-  if (hipStreamCreateWithFlags(&st->side, hipStreamNonBlocking) != hipSuccess) {
-    delete st;
-    return DPC_ERR_LAUNCH;
-  }
-  *out = st;
-  return DPC_OK;
-}
-
-int dpc_step_state_destroy(DpcStepState* state) {
-  if (!state) return DPC_OK;
-  const bool ok = hipStreamSynchronize(state->side) == hipSuccess && hipStreamDestroy(state->side) == hipSuccess;
-  delete state;
-  return ok ? DPC_OK : DPC_ERR_LAUNCH;
-}
-
-size_t dpc_step_handoff_bytes(const DpcParams* p) { return validate(p) == DPC_OK ? handoff_bytes(p) : 0; }
-
-int dpc_project_loss_step(DpcStepState* state, const DpcParams* p, const float* pc, const float* q, const float* t,
-                          const float* f, const float* s, const float* host_kern_xy, const float* host_kern_z,
-                          const float* gt, void* cells, float* grid_wh, uint64_t* mask, float* proj, float* sse, float* loss,
-                          int32_t* winner, void* workspace, float* fwd_dsmall, const float* dloss, float* dpc, float* dsmall,
-                          void* handoff, int* overlapped, void* stream) {
-  if (overlapped) *overlapped = 0;
+int dpc_project_loss_step(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
+                          const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt, void* cells,
+                          float* grid_wh, uint64_t* mask, float* proj, float* sse, float* loss, int32_t* winner,
+                          void* workspace, float* fwd_dsmall, const float* dloss, float* dpc, float* dsmall, void* stream) {
   if (!p || !loss) return DPC_ERR_NULL;
   if (p->B == 0) return hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream) == hipSuccess ? DPC_OK : DPC_ERR_LAUNCH;
   if (!gt || !sse || !winner || !workspace || !fwd_dsmall || !dsmall) return DPC_ERR_NULL;
-  if (state != nullptr && !handoff) return DPC_ERR_NULL;
   const TapPlan pz = plan_taps(host_kern_z, p->taps_z);
   if (!can_fuse_column_backward(p, pz, 1, grid_wh, proj, gt, workspace)) return DPC_ERR_UNSUPPORTED;
   const float inv_S = 1.0f / (float)p->B;
   const LossArgs lf{gt, sse, nullptr, nullptr, 1, inv_S, loss, winner, 0, nullptr};
   int rc = project_fwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, nullptr, cells, nullptr, grid_wh, nullptr, mask, proj,
-                            nullptr, lf, workspace, fwd_dsmall, (hipStream_t)stream, state, handoff, overlapped);
+                            nullptr, lf, workspace, fwd_dsmall, (hipStream_t)stream);
   if (rc != DPC_OK) return rc;
   const LossArgs lb{gt, nullptr, winner, dloss, 1, inv_S, nullptr, nullptr, 1, nullptr};
   return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, grid_wh, mask, nullptr, proj, nullptr, lb, dpc,

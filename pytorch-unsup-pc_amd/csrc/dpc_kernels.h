@@ -131,62 +131,6 @@ __device__ inline Blk block_coords(int clouds, int group = 1) {
   return k;
 }
 
-// ------------------------------------------------------------------------------------------------------
-// Hand-offs between kernels that run CONCURRENTLY (the overlapped step, dpc_project_loss_step in dpc_entry.hip).
-//
-// Launched back to back in one stream, the four kernels of the step put the whole chip through one phase at a time; what a
-// cloud's kernels really depend on is that cloud's data only.  In the overlapped step the forward slab kernel runs on a second
-// HIP stream (= a second hardware queue; kernels of one queue never overlap on this runtime, measured: tools/microbench/
-// anyorder_probe.hip) and the dependencies travel through memory instead of through the queue:
-//     k_locate  --located[b]-->  k_splat_xl  --splatted[b]-->  k_zcol_fwdbwd   (then k_gather_hw behind a kernel boundary)
-// a workgroup that has stored its part of cloud b adds 1 to the cloud's counter; a consumer workgroup of cloud b polls until
-// the counter reads epoch * parts (epoch = number of the run, counters are never reset).  The form is the one
-// MI355X_MICROARCH.md lists as valid on gfx950 ("Valid forms", first table row): EVERY handed-off byte is stored with sc1
-// (write-through) and loaded with sc1 (L2-served), every storing wave drains its stores (s_waitcnt vmcnt(0)), a workgroup
-// barrier, ONE lane's agent-scope add as the signal; the consumer's polling lane loads the counter with sc1, the other
-// waves go on behind a workgroup barrier that lane joins.  Cross-stream EVENTS are no alternative: 12 us per dependency
-// (tools/microbench/xstream_probe.hip).  Every wait is bounded (DPC_STATUS_WAIT_TIMEOUT): a lost producer cannot hang the GPU.
-// ------------------------------------------------------------------------------------------------------
-struct Handoff {
-  unsigned int* located;    // [B]  chunks of cloud b stored by k_locate
-  unsigned int* splatted;   // [B]  slabs of cloud b stored by the forward slab kernel
-  unsigned int* started;    // [1]  epoch of the newest run whose k_locate has begun (the side stream's gate waits for it)
-  int* status;              // the caller's status word | NULL
-  unsigned int epoch;       // number of this run, 1, 2, ...
-  unsigned int slabs;       // workgroups of the forward slab kernel per cloud (xl_slabs_per_cloud)
-};
-constexpr int kSc1 = 16;    // cache-policy operand of the raw-buffer builtins: sc1 (gfx940+)
-constexpr unsigned long long kWaitTicks = 200000000ull;   // 2 s of the 100 MHz realtime counter
-
-// all threads of the workgroup, after its last hand-off store
-__device__ inline void handoff_publish(unsigned int* counter) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have left it
-  __syncthreads();                                    // ... and so have every other wave's
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// all threads of the workgroup, before its first hand-off load; true = the data is there
-__device__ inline void handoff_wait(const unsigned int* counter, unsigned int target, int* status) {
-  if (threadIdx.x == 0) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((int)(__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > kWaitTicks) {
-        if (status != nullptr) atomicOr(status, (int)DPC_STATUS_WAIT_TIMEOUT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(20);
-    }
-  }
-  __syncthreads();
-}
-
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-// 2 GB window over a hand-off buffer: 32-bit byte offsets, sc1 accesses through the raw-buffer builtins (the compiler
-// tracks their completion, unlike inline-asm loads)
-__device__ inline __amdgpu_buffer_rsrc_t handoff_window(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
-}
-
 __host__ __device__ inline int points_per_set(const DpcParams& P) { return P.point_index != nullptr ? P.N_src : P.N; }
 
 __device__ inline int odd_stride(int w) { return w | 1; }  // generic LDS row stride: odd => conflict-free column walks
@@ -217,33 +161,6 @@ struct Cells {
   }
 };
 
-// sc1 (hand-off) variants of the accessors above: 32-bit offsets into a window over the whole cells buffer
-__device__ inline unsigned int cells_offset(const Cells& cells, int b, int blk) {
-  return (unsigned int)(((size_t)b * cells.nblk + blk) * cells.chunk);
-}
-template <int AUX>
-__device__ inline PointRec load_record_at(const Cells& cells, __amdgpu_buffer_rsrc_t win, int b, int blk, int pos) {
-  if constexpr (AUX == 0) {
-    return load_record(cells.recs(b, blk), pos);
-  } else {
-    const i32x4 v = __builtin_bit_cast(i32x4, __builtin_amdgcn_raw_buffer_load_b128(win, (int)(cells_offset(cells, b, blk) + pos * 16u), 0, AUX));
-    PointRec r;
-    r.code = v.x; r.tz = __int_as_float(v.y); r.ty = __int_as_float(v.z); r.tx = __int_as_float(v.w);
-    return r;
-  }
-}
-// bin offset k of a chunk (uint16 entries, read as the aligned dword that holds it)
-template <int AUX>
-__device__ inline int load_offset_at(const Cells& cells, __amdgpu_buffer_rsrc_t win, int b, int blk, int k) {
-  if constexpr (AUX == 0) {
-    return (int)cells.offs(b, blk)[k];
-  } else {
-    const unsigned int base = cells_offset(cells, b, blk) + (unsigned int)kLocThreads * 2u * (unsigned int)sizeof(PointRec);
-    const unsigned int w = __builtin_amdgcn_raw_buffer_load_b32(win, (int)(base + (k >> 1) * 4u), 0, AUX);
-    return (int)((w >> ((k & 1) * 16)) & 0xffffu);
-  }
-}
-
 // Visit every record of cloud b whose bin lies in [bin_lo, bin_hi).  f(rec, aux) with aux -> {px,py,pz,orig}.
 //   build_record_table (wave 0, before a barrier the caller already has): lane c reads chunk c's range, an
 //   inclusive scan over lanes gives every chunk's first flat index; tab = {prefix[nblk+1], begin[nblk]} in LDS.
@@ -257,14 +174,13 @@ struct RecordRange {  // wave 0, lane c: sorted range [beg, beg+cnt) of chunk c
 };
 
 // Issue the offset loads early (they are only waited for in finish_record_table, so a whole phase can run under them).
-template <int AUX = 0>
-__device__ inline RecordRange load_record_range(const Cells& cells, int b, int bin_lo, int bin_hi,
-                                                __amdgpu_buffer_rsrc_t win = __amdgpu_buffer_rsrc_t()) {
+__device__ inline RecordRange load_record_range(const Cells& cells, int b, int bin_lo, int bin_hi) {
   RecordRange r{0, 0};
   const int c = threadIdx.x;
   if (c < DPC_WAVE && c < cells.nblk) {
-    r.beg = load_offset_at<AUX>(cells, win, b, c, bin_lo);
-    r.cnt = load_offset_at<AUX>(cells, win, b, c, bin_hi) - r.beg;
+    const uint16_t* offs = cells.offs(b, c);
+    r.beg = offs[bin_lo];
+    r.cnt = (int)offs[bin_hi] - r.beg;
   }
   return r;
 }
@@ -295,14 +211,13 @@ __device__ inline void flat_lookup(const int* tab, int j, int& chunk, int& pos) 
   pos = tab[DPC_WAVE + 1 + lo] + (j - tab[lo]);
 }
 
-template <int AUX = 0, class F>
-__device__ inline void for_each_record_flat(const Cells& cells, int b, const int* tab, F f, int first = 0,
-                                            __amdgpu_buffer_rsrc_t win = __amdgpu_buffer_rsrc_t()) {
+template <class F>
+__device__ inline void for_each_record_flat(const Cells& cells, int b, const int* tab, F f, int first = 0) {
   const int total = tab[DPC_WAVE];
   for (int j = first + threadIdx.x; j < total; j += blockDim.x) {
     int c, pos;
     flat_lookup(tab, j, c, pos);
-    f(load_record_at<AUX>(cells, win, b, c, pos), cells.aux(b, c) + pos);
+    f(load_record(cells.recs(b, c), pos), cells.aux(b, c) + pos);
   }
 }
 
@@ -885,7 +800,7 @@ __device__ inline void camgrad_publish(double tot, int tid, const CameraRaw& raw
 
 // ---- launchers defined next to their kernels (bucket = compile-time tap radius bucket chosen by plan_taps) ----
 int launch_locate(const DpcParams* p, int src, const void* pts, const float* q, const float* t, const float* f, float* tr_pc,
-                  void* cells, hipStream_t st, const Handoff* ho = nullptr);
+                  void* cells, hipStream_t st);
 int launch_splat(int bucket, const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* raw, float* Tbuf,
                  uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st);
 int launch_gather(int bucket, const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
@@ -895,8 +810,7 @@ int launch_zcol_fwd(const DpcParams* p, const float* host_kern_z, const TapPlan&
                     float* smoothed, float* proj, float* trans, const LossArgs& la, hipStream_t st);
 int launch_zcol_fwdbwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* Tbuf, const float* s,
                        float* proj, float* dT, float* ds_part, int ntile, unsigned long long* tickets, float* bwd_dsmall,
-                       unsigned int* cg_count, const LossArgs& la, hipStream_t st, const Handoff* ho = nullptr);
-bool zcol_handoff_applies(const DpcParams* p, const TapPlan& pz);
+                       unsigned int* cg_count, const LossArgs& la, hipStream_t st);
 int launch_zcol_bwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* grid_wh, const float* s,
                     const float* dproj, const float* proj, const float* trans, float* dT, float* ds_part, float* dsmall,
                     unsigned int* cg_count, const float* dgrid_extra, const LossArgs& la, hipStream_t st);
@@ -905,10 +819,6 @@ int launch_loss_finalize(const float* sse_tiles, int ntile, float* sse, int S, i
 // dpc_slab_xl.hip: the x-in-lanes slab kernels (64 x 64 planes, radius bucket 1..6); DPC_NO_XL builds keep the older kernels
 bool xl_applies(const DpcParams* p, int bucket);
 int launch_splat_xl(int bucket, const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* Tbuf, uint64_t* mask,
-                    float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st,
-                    const Handoff* ho = nullptr);
-int launch_gate(const Handoff& ho, hipStream_t st);
-int xl_slabs_per_cloud(const DpcParams* p);
-int xl_planes_per_slab();
+                    float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st);
 
 }  // namespace dpck

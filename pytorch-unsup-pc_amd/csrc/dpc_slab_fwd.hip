@@ -13,12 +13,11 @@ namespace {
 //   SRC = 0: pc/q/t/f -> camera transform (pc_perspective_transform), optional tr_pc output
 //   SRC = 1: points are already transformed, fp32 (z,y,x);  SRC = 2: same, fp64
 // ------------------------------------------------------------------------------------------------------
-//   HO: overlapped step -- the chunk is stored write-through (sc1) and published on the cloud's `located` counter
-template <int SRC, bool HO = false>
+template <int SRC>
 __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void* __restrict__ pts,
                                                         const float* __restrict__ q, const float* __restrict__ t,
                                                         const float* __restrict__ f, float* __restrict__ tr_pc,
-                                                        uint8_t* __restrict__ cells_out, Handoff ho) {
+                                                        uint8_t* __restrict__ cells_out) {
   // Counting sort by bin that is STABLE without any ordered atomic: every thread sets its own bit in its bin's 256-bit
   // membership mask (ds_or, result independent of arrival order); a bin's population is the popcount of its mask and a
   // point's rank inside the bin the popcount below its own bit.  (Ranks handed out by an atomic counter are arrival order,
@@ -28,11 +27,6 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
   extern __shared__ __attribute__((aligned(16))) unsigned int member[];   // (D + 1) x 8 words, sized by the launch
   const Blk bk = block_coords(P.B);
   const int b = bk.y, blk = bk.x, tid = threadIdx.x;
-  // the LAST workgroup of this run has begun, so every workgroup of the grid is resident or done (dispatch is in block
-  // order): the side stream's gate lets the slab kernel through -- any earlier and its 141 KB workgroups would take the CUs
-  // from the chunks that are still waiting for one (measured: k_locate 9 -> 16 us)
-  if (HO && blockIdx.x == gridDim.x - 1 && tid == 0)
-    __hip_atomic_store(ho.started, ho.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const int D = P.D, nbins = D + 1;
   const int i = blk * kLocThreads + tid;
   // N is the capacity of the call; a device-side count of live points (a scheduled keep-count under graph replay) may cut
@@ -133,30 +127,14 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
   }
   __syncthreads();
   const size_t chunk = chunk_bytes(D);
+  uint8_t* out = cells_out + ((size_t)b * bk.nx + blk) * chunk;
   const int npts = min(kLocThreads, P.N - blk * kLocThreads);
-  if constexpr (HO) {
-    const __amdgpu_buffer_rsrc_t win = handoff_window(cells_out);
-    const unsigned int base = (unsigned int)(((size_t)b * bk.nx + blk) * chunk);
-    if (tid < npts) {
-      const int4 r = stage[tid], a = stage[kLocThreads + tid];
-      __builtin_amdgcn_raw_buffer_store_b128(i32x4{r.x, r.y, r.z, r.w}, win, (int)(base + tid * 16u), 0, kSc1);
-      __builtin_amdgcn_raw_buffer_store_b128(i32x4{a.x, a.y, a.z, a.w}, win, (int)(base + (unsigned int)kLocThreads * 16u + tid * 16u), 0, kSc1);
-    }
-    // bin offsets as dwords of two uint16 (nbins + 1 entries; an odd tail entry shares its dword with padding)
-    for (int k2 = tid; 2 * k2 < nbins + 1; k2 += kLocThreads) {
-      const unsigned int lo = (unsigned int)hist[2 * k2] & 0xffffu, hi = 2 * k2 + 1 < nbins + 1 ? (unsigned int)hist[2 * k2 + 1] & 0xffffu : 0u;
-      __builtin_amdgcn_raw_buffer_store_b32(lo | (hi << 16), win, (int)(base + (unsigned int)kLocThreads * 32u + k2 * 4u), 0, kSc1);
-    }
-    handoff_publish(ho.located + b);
-  } else {
-    uint8_t* out = cells_out + ((size_t)b * bk.nx + blk) * chunk;
-    if (tid < npts) {
-      reinterpret_cast<int4*>(out)[tid] = stage[tid];
-      reinterpret_cast<int4*>(out + (size_t)kLocThreads * sizeof(PointRec))[tid] = stage[kLocThreads + tid];
-    }
-    uint16_t* offs = reinterpret_cast<uint16_t*>(out + (size_t)kLocThreads * 2 * sizeof(PointRec));
-    for (int k = tid; k < nbins + 1; k += kLocThreads) offs[k] = (uint16_t)hist[k];
+  if (tid < npts) {
+    reinterpret_cast<int4*>(out)[tid] = stage[tid];
+    reinterpret_cast<int4*>(out + (size_t)kLocThreads * sizeof(PointRec))[tid] = stage[kLocThreads + tid];
   }
+  uint16_t* offs = reinterpret_cast<uint16_t*>(out + (size_t)kLocThreads * 2 * sizeof(PointRec));
+  for (int k = tid; k < nbins + 1; k += kLocThreads) offs[k] = (uint16_t)hist[k];
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -442,18 +420,14 @@ int launch_splat(int bucket, const DpcParams* p, Cells cells, const float* kxy, 
 }
 
 int launch_locate(const DpcParams* p, int src, const void* pts, const float* q, const float* t, const float* f,
-                  float* tr_pc, void* cells, hipStream_t st, const Handoff* ho) {
+                  float* tr_pc, void* cells, hipStream_t st) {
   if (p->N == 0 || p->B == 0) return DPC_OK;
   dim3 g(num_chunks(p->N) * p->B), blk(kLocThreads);
   uint8_t* out = static_cast<uint8_t*>(cells);
   const size_t lds = (size_t)(p->D + 1) * (kLocThreads / 32) * sizeof(unsigned int);  // the bins' membership masks
-  const Handoff none{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
-  if (ho != nullptr) {
-    if (src != 0) return DPC_ERR_UNSUPPORTED;
-    DPC_LAUNCH("k_locate", (k_locate<0, true>), g, blk, lds, st, *p, pts, q, t, f, tr_pc, out, *ho);
-  } else if (src == 0) DPC_LAUNCH("k_locate", (k_locate<0, false>), g, blk, lds, st, *p, pts, q, t, f, tr_pc, out, none);
-  else if (src == 1) DPC_LAUNCH("k_locate", (k_locate<1, false>), g, blk, lds, st, *p, pts, q, t, f, tr_pc, out, none);
-  else DPC_LAUNCH("k_locate", (k_locate<2, false>), g, blk, lds, st, *p, pts, q, t, f, tr_pc, out, none);
+  if (src == 0) DPC_LAUNCH("k_locate", k_locate<0>, g, blk, lds, st, *p, pts, q, t, f, tr_pc, out);
+  else if (src == 1) DPC_LAUNCH("k_locate", k_locate<1>, g, blk, lds, st, *p, pts, q, t, f, tr_pc, out);
+  else DPC_LAUNCH("k_locate", k_locate<2>, g, blk, lds, st, *p, pts, q, t, f, tr_pc, out);
   return launch_ok();
 }
 

@@ -66,19 +66,23 @@ __device__ inline float wpass_lanes(float v, const TapsT<RB>& taps) {
 // one x -> clamp mask words by ballot -> H pass in registers -> W pass across lanes -> T.     grid (D/ZS) x B, ZS*256 threads
 //   accumulator planes carry RB zero rows above and below (the zero padding of the H pass)
 // ------------------------------------------------------------------------------------------------------
-//   HO: overlapped step (dpc_kernels.h, Handoff) -- the workgroup waits for its cloud's chunks, reads them with sc1 loads,
-//   stores T, the clamp mask and the zeroed loss words write-through and publishes its slab on the cloud's `splatted` counter
-template <int ZS, int RB, bool HO>
+template <int ZS, int RB>
 __global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells, TapsT<RB> taps_arg, float* __restrict__ Tbuf,
                                                        uint64_t* __restrict__ mask, float* __restrict__ sse,
                                                        float* __restrict__ loss_zero, int* __restrict__ winner_zero,
-                                                       unsigned long long* __restrict__ ticket_zero, Handoff ho) {
+                                                       unsigned long long* __restrict__ ticket_zero) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
   constexpr int NT = ZS * 256, PR = kXG + 2 * RB, ACC = ZS * PR * kXG, WIN = kXSeg + 2 * RB;
-  constexpr int AUX = HO ? kSc1 : 0;
   static_assert(ACC % 4 == 0, "zero fill in 16-byte words, two halves");
   const TapsT<RB> taps = resolve_taps<RB>(taps_arg, P.dev_taps_xy, P.taps_xy, false);
   const Blk bk = block_coords(P.B);
+  if (sse != nullptr && bk.x == 0 && threadIdx.x == 0) {  // the ray-march kernel accumulates into these
+    sse[bk.y] = 0.f;
+    if (winner_zero != nullptr) winner_zero[bk.y] = 0;
+    if (ticket_zero != nullptr) ticket_zero[bk.y] = 0ull;
+    if (ticket_zero != nullptr && bk.y == 0) ticket_zero[bk.ny] = 0ull;
+    if (loss_zero != nullptr && bk.y == 0) *loss_zero = 0.f;
+  }
   const int D = P.D;
   const int b = bk.y, z0 = bk.x * ZS;
   const int nz = min(ZS, D - z0);
@@ -87,37 +91,13 @@ __global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells,
   f32x4* s4 = reinterpret_cast<f32x4*>(slab);
   int* tab = reinterpret_cast<int*>(acc + ACC);
   const bool flat = cells.nblk <= DPC_WAVE;
-  const __amdgpu_buffer_rsrc_t cwin = handoff_window(cells.base);
   DPC_STAMP(0);
   // offsets | zero A | table | barrier | records -> registers | zero B | barrier | atomics  (see k_splat_hw)
   constexpr int PRE = 2, ZH = (ACC / 2) / 2;
   RecordRange rr{0, 0};
-  if constexpr (HO) {
-    // nothing of the cloud may be read before its chunks are published: the whole zero fill runs under the wait instead
-    for (int i = tid; i < ACC / 2; i += NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    handoff_wait(ho.located + b, ho.epoch * (unsigned int)cells.nblk, ho.status);
-    rr = load_record_range<AUX>(cells, b, max(z0 - 1, 0), z0 + nz, cwin);
-    finish_record_table(rr, tab);
-  } else {
-    if (flat) rr = load_record_range(cells, b, max(z0 - 1, 0), z0 + nz);
-    for (int i = tid; i < ZH; i += NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (flat) finish_record_table(rr, tab);
-  }
-  if (sse != nullptr && bk.x == 0 && tid == 0) {  // the ray-march kernel accumulates into these
-    if constexpr (HO) {   // ... from another stream: write-through, in front of this workgroup's publication
-      __hip_atomic_store(sse + bk.y, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (winner_zero != nullptr) __hip_atomic_store(winner_zero + bk.y, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (ticket_zero != nullptr) __hip_atomic_store(ticket_zero + bk.y, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (ticket_zero != nullptr && bk.y == 0) __hip_atomic_store(ticket_zero + bk.ny, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (loss_zero != nullptr && bk.y == 0) __hip_atomic_store(loss_zero, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      sse[bk.y] = 0.f;
-      if (winner_zero != nullptr) winner_zero[bk.y] = 0;
-      if (ticket_zero != nullptr) ticket_zero[bk.y] = 0ull;
-      if (ticket_zero != nullptr && bk.y == 0) ticket_zero[bk.ny] = 0ull;
-      if (loss_zero != nullptr && bk.y == 0) *loss_zero = 0.f;
-    }
-  }
+  if (flat) rr = load_record_range(cells, b, max(z0 - 1, 0), z0 + nz);
+  for (int i = tid; i < ZH; i += NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (flat) finish_record_table(rr, tab);
   __syncthreads();
   PointRec pre[PRE];
   int npre = 0;
@@ -130,15 +110,13 @@ __global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells,
       if (j < total) {
         int c, pos;
         flat_lookup(tab, j, c, pos);
-        pre[r] = load_record_at<AUX>(cells, cwin, b, c, pos);
+        pre[r] = load_record(cells.recs(b, c), pos);
       }
     }
     npre = PRE * NT;
   }
-  if constexpr (!HO) {
-    for (int i = ZH + tid; i < ACC / 2; i += NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-  }
+  for (int i = ZH + tid; i < ACC / 2; i += NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
   DPC_STAMP(1);
   auto scatter = [&](const PointRec& rec, const int4*) {
     const Cell c = cell_from_record(rec);
@@ -162,9 +140,9 @@ __global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells,
 #pragma unroll
     for (int r = 0; r < PRE; ++r)
       if (pre[r].code >= 0) scatter(pre[r], nullptr);
-    for_each_record_flat<AUX>(cells, b, tab, scatter, npre, cwin);
+    for_each_record_flat(cells, b, tab, scatter, npre);
   } else {
-    for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, scatter);   // (never with HO: the host requires the flat table)
+    for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, scatter);
   }
   __syncthreads();
   DPC_STAMP(2);
@@ -173,98 +151,56 @@ __global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells,
   const int lane = tid & (DPC_WAVE - 1);
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int zz = w % ZS, y0 = (w / ZS) * kXSeg;
-  if (zz < nz) {   // (always with HO: the host requires D % ZS == 0)
-    const unsigned long long* col = acc + ((size_t)zz * PR + y0) * kXG + lane;  // window row i = grid row y0 + i - RB
-    unsigned long long a[WIN];
+  if (zz >= nz) return;
+  const unsigned long long* col = acc + ((size_t)zz * PR + y0) * kXG + lane;  // window row i = grid row y0 + i - RB
+  unsigned long long a[WIN];
 #pragma unroll
-    for (int i = 0; i < WIN; ++i) a[i] = col[i * kXG];
-    // clamp mask: bit x of word y <=> raw <= 1 (raw >= 0 always); 64 lanes = the 64 bits of the row's word.  Lane j keeps
-    // row j's word: the 16 words of this wave leave in one 128-byte store.
-    const size_t mword0 = ((size_t)b * D + z0 + zz) * kXG + y0;
-    unsigned long long mword = 0ull;
+  for (int i = 0; i < WIN; ++i) a[i] = col[i * kXG];
+  // clamp mask: bit x of word y <=> raw <= 1 (raw >= 0 always); 64 lanes = the 64 bits of the row's word.  Lane j keeps
+  // row j's word: the 16 words of this wave leave in one 128-byte store.
+  unsigned long long* mask_out = reinterpret_cast<unsigned long long*>(mask) + ((size_t)b * D + z0 + zz) * kXG + y0;
+  unsigned long long mword = 0ull;
 #pragma unroll
-    for (int j = 0; j < kXSeg; ++j) {
-      const unsigned long long bits = __ballot(a[RB + j] <= kFixOne);
-      mword = lane == j ? bits : mword;
-    }
-    if (lane < kXSeg) {
-      if constexpr (HO)
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{(unsigned int)mword, (unsigned int)(mword >> 32)}, handoff_window(mask),
-                                              (int)((mword0 + lane) * 8u), 0, kSc1);
-      else
-        reinterpret_cast<unsigned long long*>(mask)[mword0 + lane] = mword;
-    }
-    float v[WIN];
-#pragma unroll
-    for (int i = 0; i < WIN; ++i) v[i] = fminf(from_fixed(a[i]), 1.0f);
-    DPC_STAMP(3);
-    // four rows at a time: H pass in registers, W pass across the lanes, then the quad transpose so that every lane stores
-    // 16 contiguous bytes (lane 4q+e: row j+e, x = 4q .. 4q+3)
-    const size_t t0 = (((size_t)b * D + z0 + zz) * kXG + y0 + (lane & 3)) * kXG + (lane & ~3);
-    const __amdgpu_buffer_rsrc_t twin = handoff_window(Tbuf);
-#pragma unroll
-    for (int j = 0; j < kXSeg; j += 4) {
-      float o[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float h = 0.f;
-#pragma unroll
-        for (int tp = 0; tp < 2 * RB + 1; ++tp) h = fmaf(taps.w[tp], v[j + e + tp], h);
-        o[e] = wpass_lanes<RB>(h, taps);
-      }
-      quad_transpose(o, lane);
-      if constexpr (HO)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, f32x4{o[0], o[1], o[2], o[3]}), twin,
-                                               (int)((t0 + (size_t)j * kXG) * 4u), 0, kSc1);
-      else
-        *reinterpret_cast<f32x4*>(Tbuf + t0 + (size_t)j * kXG) = f32x4{o[0], o[1], o[2], o[3]};
-    }
-    DPC_STAMP(5);
+  for (int j = 0; j < kXSeg; ++j) {
+    const unsigned long long bits = __ballot(a[RB + j] <= kFixOne);
+    mword = lane == j ? bits : mword;
   }
-  if constexpr (HO) handoff_publish(ho.splatted + b);
+  if (lane < kXSeg) mask_out[lane] = mword;
+  float v[WIN];
+#pragma unroll
+  for (int i = 0; i < WIN; ++i) v[i] = fminf(from_fixed(a[i]), 1.0f);
+  DPC_STAMP(3);
+  // four rows at a time: H pass in registers, W pass across the lanes, then the quad transpose so that every lane stores
+  // 16 contiguous bytes (lane 4q+e: row j+e, x = 4q .. 4q+3)
+  float* Tout = Tbuf + (((size_t)b * D + z0 + zz) * kXG + y0 + (lane & 3)) * kXG + (lane & ~3);
+#pragma unroll
+  for (int j = 0; j < kXSeg; j += 4) {
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float h = 0.f;
+#pragma unroll
+      for (int tp = 0; tp < 2 * RB + 1; ++tp) h = fmaf(taps.w[tp], v[j + e + tp], h);
+      o[e] = wpass_lanes<RB>(h, taps);
+    }
+    quad_transpose(o, lane);
+    *reinterpret_cast<f32x4*>(Tout + (size_t)j * kXG) = f32x4{o[0], o[1], o[2], o[3]};
+  }
+  DPC_STAMP(5);
 }
 
 template <int ZS, int RB>
 int launch_splat_xl_zr(const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* Tbuf, uint64_t* mask,
-                       float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st,
-                       const Handoff* ho) {
+                       float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st) {
   constexpr size_t lds = (size_t)ZS * (kXG + 2 * RB) * kXG * sizeof(unsigned long long) + kTabInts * sizeof(int);
   static_assert(lds <= kLdsLimit, "forward slab does not fit LDS");
-  const dim3 grid(((p->D + ZS - 1) / ZS) * p->B), block(ZS * 256);
-  if (ho != nullptr) {
-    // hand-off mode: whole slabs only, the flat record table, 32-bit offsets into the grid
-    if (p->D % ZS != 0 || cells.nblk > DPC_WAVE || (size_t)p->B * p->D * kXG * kXG * sizeof(float) >= 0x7fffffffull) return DPC_ERR_UNSUPPORTED;
-    auto kern = k_splat_xl<ZS, RB, true>;
-    static LdsLimit limit;
-    int rc = set_lds(kern, lds, limit);
-    if (rc != DPC_OK) return rc;
-    DPC_LAUNCH("k_splat_xl", kern, grid, block, lds, st, *p, cells, make_taps<RB>(kxy, pxy, false), Tbuf, mask, sse, loss_zero,
-               winner_zero, ticket_zero, *ho);
-    return launch_ok();
-  }
-  auto kern = k_splat_xl<ZS, RB, false>;
+  auto kern = k_splat_xl<ZS, RB>;
   static LdsLimit limit;
   int rc = set_lds(kern, lds, limit);
   if (rc != DPC_OK) return rc;
-  DPC_LAUNCH("k_splat_xl", kern, grid, block, lds, st, *p, cells, make_taps<RB>(kxy, pxy, false), Tbuf, mask, sse, loss_zero,
-             winner_zero, ticket_zero, Handoff{nullptr, nullptr, nullptr, nullptr, 0u, 0u});
+  DPC_LAUNCH("k_splat_xl", kern, dim3(((p->D + ZS - 1) / ZS) * p->B), dim3(ZS * 256), lds, st, *p, cells,
+             make_taps<RB>(kxy, pxy, false), Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
   return launch_ok();
-}
-
-// The side stream's gate in front of the slab kernel of run `epoch`: one wave that returns once that run's k_locate has
-// begun.  Kernels of one stream are dispatched in order, so the slab kernel's workgroups (141 KB of LDS each: they would
-// keep the PREVIOUS run's backward slab kernel off the CUs) do not become resident while the previous run is still at work.
-__global__ __launch_bounds__(64) void k_gate(Handoff ho) {
-  if (threadIdx.x == 0) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while ((int)(__hip_atomic_load(ho.started, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ho.epoch) < 0) {
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 30 * kWaitTicks) {   // a minute: whatever runs in front of k_locate may take long
-        if (ho.status != nullptr) atomicOr(ho.status, (int)DPC_STATUS_WAIT_TIMEOUT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(40);
-    }
-  }
 }
 
 }  // namespace
@@ -278,25 +214,16 @@ bool xl_applies(const DpcParams* p, int bucket) {
 #define DPC_XL_FWD_ZS 4   // planes per forward slab: 4 -> one 1024-thread workgroup per CU, 2 -> two 512-thread workgroups per CU
 #endif
 int launch_splat_xl(int bucket, const DpcParams* p, Cells cells, const float* kxy, const TapPlan& pxy, float* Tbuf, uint64_t* mask,
-                    float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st,
-                    const Handoff* ho) {
+                    float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st) {
   constexpr int ZS = DPC_XL_FWD_ZS;
   switch (bucket) {
-    case 1: return launch_splat_xl_zr<ZS, 1>(p, cells, kxy, pxy, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st, ho);
-    case 2: return launch_splat_xl_zr<ZS, 2>(p, cells, kxy, pxy, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st, ho);
-    case 3: return launch_splat_xl_zr<ZS, 3>(p, cells, kxy, pxy, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st, ho);
-    case 4: return launch_splat_xl_zr<ZS, 4>(p, cells, kxy, pxy, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st, ho);
-    case 6: return launch_splat_xl_zr<ZS, 6>(p, cells, kxy, pxy, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st, ho);
+    case 1: return launch_splat_xl_zr<ZS, 1>(p, cells, kxy, pxy, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
+    case 2: return launch_splat_xl_zr<ZS, 2>(p, cells, kxy, pxy, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
+    case 3: return launch_splat_xl_zr<ZS, 3>(p, cells, kxy, pxy, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
+    case 4: return launch_splat_xl_zr<ZS, 4>(p, cells, kxy, pxy, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
+    case 6: return launch_splat_xl_zr<ZS, 6>(p, cells, kxy, pxy, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, st);
   }
   return DPC_ERR_TAPS;
-}
-
-int xl_planes_per_slab() { return DPC_XL_FWD_ZS; }
-int xl_slabs_per_cloud(const DpcParams* p) { return (p->D + DPC_XL_FWD_ZS - 1) / DPC_XL_FWD_ZS; }
-
-int launch_gate(const Handoff& ho, hipStream_t st) {
-  hipLaunchKernelGGL(k_gate, dim3(1), dim3(64), 0, st, ho);
-  return launch_ok();
 }
 
 }  // namespace dpck

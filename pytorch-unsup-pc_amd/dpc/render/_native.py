@@ -21,7 +21,7 @@ COL_DQ, COL_DS, COL_DT, COL_DF = 0, 4, 5, 8
 DPC_ERR_SHAPE = -2
 DPC_ERR_TAPS = -3
 DPC_ERR_LDS = -4
-DPC_STATUS_BAD_INDEX, DPC_STATUS_WAIT_TIMEOUT = 1, 2
+DPC_STATUS_BAD_INDEX = 1
 
 # every symbol include/dpc_render.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = (
@@ -29,7 +29,7 @@ SYMBOLS = (
     "dpc_project_fwd", "dpc_project_bwd", "dpc_project_loss_fwd", "dpc_project_loss_bwd", "dpc_transform_fwd", "dpc_transform_bwd",
     "dpc_splat_fwd", "dpc_splat_bwd", "dpc_smooth", "dpc_drc_fwd", "dpc_drc_bwd",
     "dpc_silhouette_loss", "dpc_point_dropout_indices", "dpc_point_dropout_indices_live", "dpc_schedule_update", "dpc_taps_bucket",
-    "dpc_step_state_create", "dpc_step_state_destroy", "dpc_step_handoff_bytes", "dpc_project_loss_step",
+    "dpc_project_loss_step",
     "dpc_nearest_workspace_bytes", "dpc_point_cloud_distance", "dpc_profile_enable", "dpc_profile_disable", "dpc_profile_count", "dpc_profile_get", "dpc_profile_pair_overhead",
 )
 
@@ -109,14 +109,8 @@ def lib():
         L.dpc_schedule_update.argtypes = [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]
         L.dpc_taps_bucket.restype = ctypes.c_int
         L.dpc_taps_bucket.argtypes = [vp, ctypes.c_int]
-        L.dpc_step_state_create.restype = ctypes.c_int
-        L.dpc_step_state_create.argtypes = [ctypes.POINTER(vp)]
-        L.dpc_step_state_destroy.restype = ctypes.c_int
-        L.dpc_step_state_destroy.argtypes = [vp]
-        L.dpc_step_handoff_bytes.restype = ctypes.c_size_t
-        L.dpc_step_handoff_bytes.argtypes = [pp]
         L.dpc_project_loss_step.restype = ctypes.c_int
-        L.dpc_project_loss_step.argtypes = [vp, pp] + [vp] * 21 + [ctypes.POINTER(ctypes.c_int), vp]
+        L.dpc_project_loss_step.argtypes = [pp] + [vp] * 21
         if L.dpc_abi_version() != ABI_VERSION:
             raise RuntimeError("dpc.render: libdpc_render.so ABI %d, expected %d -- rebuild it (make -C %s)"
                                % (L.dpc_abi_version(), ABI_VERSION, _CSRC))

@@ -1450,51 +1450,34 @@ def test_device_schedule_follows_sigma_and_keep_count_under_replay(R, O):
     assert full.shape == (B, 123) and torch.equal(part[:, :123], full)
 
 
-@pytest.mark.parametrize("B,N,sig", [(8, 3000, 0.64), (32, 8000, 0.64), (5, 700, 1.0)])
-def test_overlapped_step_is_bit_identical_to_the_plain_sequence(R, O, B, N, sig):
-    """dpc_project_loss_step: the four kernels of a step overlapped on two HIP streams, the dependencies carried by
-    per-cloud counters in memory (write-through stores, bounded polls).  Against the same plan run as the plain launch
-    sequence and against the autograd entry point, bit for bit, over many back-to-back runs with inputs that change from
-    run to run (a stale read of the previous run's data would show), with other work keeping the GPU busy in between."""
-    G = 64
-    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=21)
+@pytest.mark.parametrize("B,N,G,ksz,sig", [(8, 3000, 64, 21, 0.64), (5, 700, 32, 11, 1.3), (3, 1500, 64, 21, 3.0)])
+def test_step_plan_is_bit_identical_to_the_autograd_path(R, O, B, N, G, ksz, sig):
+    """dpc_project_loss_step / ProjectLossStep (forward + backward of the fused loss as one native call on static buffers)
+    against pointcloud_project_loss + backward, bit for bit, over back-to-back runs with inputs that change from run to run."""
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=ksz)
     kern = R.smoothing_kernel(cfg, sig)
     d = torch.device("cuda")
-    sets = []
+    sets, want = [], []
     for k in range(3):
         pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 9100 + k)
         sets.append([dev(x) for x in (pc, q, s, gt)])
-    over = R.project_loss_step(cfg, kern, B, N, d, overlap=True)
-    plain = R.project_loss_step(cfg, kern, B, N, d, overlap=False)
-    R.check_status()
-    want = []
-    for pc, q, s, gt in sets:
-        plain.run(pc, q, s, gt)
-        torch.cuda.synchronize()
-        assert plain.overlapped.value == 0
-        want.append([x.clone() for x in (plain.loss, plain.proj, plain.dpc, plain.dq, plain.ds, plain.winner)])
-        a, b_, c = (x.clone().requires_grad_(True) for x in (pc, q, s))
-        loss, out, _ = R.pointcloud_project_loss(cfg, a, b_, None, None, kern, scaling_factor=c, gt=gt, num_candidates=1)
-        loss.backward()
-        assert torch.equal(loss, want[-1][0]) and torch.equal(out["proj"], want[-1][1])
-        assert torch.equal(a.grad, want[-1][2]) and torch.equal(b_.grad, want[-1][3]) and torch.equal(c.grad, want[-1][4])
-    noise = torch.randn(1 << 22, device=d)
-    for it in range(120):
+        a, b_, c = (x.clone().requires_grad_(True) for x in sets[-1][:3])
+        loss, out, win = R.pointcloud_project_loss(cfg, a, b_, None, None, kern, scaling_factor=c, gt=sets[-1][3], num_candidates=1)
+        (0.5 * loss).backward()
+        want.append([x.clone() for x in (loss.detach(), out["proj"], a.grad, b_.grad, c.grad, win)])
+    plan = R.project_loss_step(cfg, kern, B, N, d)
+    half = torch.full((), 0.5, device=d)
+    for it in range(12):
         k = (it * 7 + it // 5) % 3
         pc, q, s, gt = sets[k]
-        over.run(pc, q, s, gt)
-        if it % 3 == 0:
-            noise = noise * 1.0001 + 0.5    # other kernels in the stream between two steps
+        plan.run(pc, q, s, gt, dloss=half)
         if it % 4 != 1:
-            torch.cuda.synchronize()        # some steps are checked right away, others run back to back first
-        got = (over.loss, over.proj, over.dpc, over.dq, over.ds, over.winner)
-        if it % 4 != 1:
-            for g, w, name in zip(got, want[k], ("loss", "proj", "dpc", "dq", "ds", "winner")):
-                assert torch.equal(g, w), "overlapped step, run %d: %s differs" % (it, name)
-    torch.cuda.synchronize()
-    assert over.overlapped.value == 1, "the configuration should have taken the overlapped schedule"
-    assert R.check_status() == 0
-    over.close(), plain.close()
+            torch.cuda.synchronize()
+            for g, w, name in zip((plan.loss, plan.proj, plan.dpc, plan.dq, plan.ds, plan.winner), want[k],
+                                  ("loss", "proj", "dpc", "dq", "ds", "winner")):
+                assert torch.equal(g, w), "step plan, run %d: %s differs" % (it, name)
+    with pytest.raises(ValueError):
+        plan.run(sets[0][0].double(), sets[0][1], sets[0][2], sets[0][3])
 
 
 def test_zz_error_report():

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""c2 step time of the ProjectLossStep plan: overlapped vs plain launch sequence vs HIP-graph replay of the autograd path.
+"""c2 step time of the ProjectLossStep plan (one native call per step).
    python tools/bench_step.py [steps]"""
 import os, sys, time
 os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
@@ -30,16 +30,11 @@ def timed(fn, n):
     return (time.perf_counter() - t0) / n * 1e6, t_host / n * 1e6
 
 
-res = {}
-for name, ov in (("plan, plain sequence", False), ("plan, overlapped", True)):
-    plan = R.project_loss_step(cfg, kern, B, N, d, overlap=ov)
-    us, host = timed(lambda: plan.run(pc, q, s, gt), steps)
-    print("%-24s %.2f us per step (%.0f clouds/s), host %.1f us per call, overlapped=%d, loss %.6f"
-          % (name, us, B / us * 1e6, host, plan.overlapped.value, float(plan.loss)))
-    res[name] = [x.clone() for x in (plan.loss, plan.proj, plan.dpc, plan.dq, plan.ds)]
-    from dpc.render import _native
-    prof = _native.profile_kernels(lambda: [plan.run(pc, q, s, gt) for _ in range(30)], d)
-    print("    per-kernel event times (us):", {k: round(1e3 * sum(v[10:]) / len(v[10:]), 2) for k, v in prof.items()})
-    plan.close()
-print("bit-identical:", all(torch.equal(a, b) for a, b in zip(res["plan, plain sequence"], res["plan, overlapped"])))
+plan = R.project_loss_step(cfg, kern, B, N, d)
+plan.bind(pc, q, s, gt)
+us, host = timed(plan.run, steps)
+print("native step plan: %.2f us per step (%.0f clouds/s), host %.1f us per call, loss %.6f" % (us, B / us * 1e6, host, float(plan.loss)))
+from dpc.render import _native
+prof = _native.profile_kernels(lambda: [plan.run() for _ in range(30)], d)
+print("    per-kernel event times (us):", {k: round(1e3 * sum(v[10:]) / len(v[10:]), 2) for k, v in prof.items()})
 print("status word:", R.check_status())
