@@ -76,12 +76,59 @@ def _hamilton(a, b):
                         aw * bz + az * bw + ax * by - ay * bx), dim=-1)
 
 
+# The reference's gradient w.r.t. the pose quaternion is a sum over all N points that torch takes in FP32 (the first
+# Hamilton product runs in the inputs' fp32, and the backward of broadcasting q over the points is an fp32 sum); the summed
+# vector is dominated by its radial part (|.| ~ 100..1000 for N ~ 1000..8000), which the normalisation's backward then
+# projects out -- so the reference's own d(q) carries rounding noise of about ulp(radial part), up to the size of the 1e-5
+# parity rule when |d(q)| is O(1) (measured: 1.6e-5 at N = 1300, tools/diag_precision.py, tests/test_gpu_parity.py::
+# test_pose_gradient_against_the_reference_and_its_exact_sum).  EXACT_POSE_GRADIENT = True computes the SAME forward values
+# (bit for bit) with that one sum and the normalisation's backward in fp64: the reference's gradient without its own
+# summation noise, which is what a device result can meaningfully be held to the rule against.  The default (False) is the
+# reference op for op, pinned by the golden vectors.
+EXACT_POSE_GRADIENT = False
+
+
+def _conj_mul(g, b):   # g (x) conj(b): gradient of a (x) b w.r.t. a
+    bw, bx, by, bz = b.unbind(-1)
+    return _hamilton(g, torch.stack((bw, -bx, -by, -bz), dim=-1))
+
+
+def _mul_conj(a, g):   # conj(a) (x) g: gradient of a (x) b w.r.t. b
+    aw, ax, ay, az = a.unbind(-1)
+    return _hamilton(torch.stack((aw, -ax, -ay, -az), dim=-1), g)
+
+
+class _FirstProductExactSum(torch.autograd.Function):
+    """qn (x) (0,p) with the reference's fp32 forward arithmetic; backward in fp64, the sum over the points included.
+    qn arrives as an fp64 tensor holding the reference's fp32 values."""
+
+    @staticmethod
+    def forward(ctx, qn, p4):
+        ctx.save_for_backward(qn, p4)
+        return _hamilton(qn.to(p4.dtype), p4)
+
+    @staticmethod
+    def backward(ctx, g):
+        qn, p4 = ctx.saved_tensors
+        g64, q64, p64 = g.to(F64), qn.to(F64), p4.to(F64)
+        dq = _conj_mul(g64, p64).sum(1, keepdim=True)          # fp64 sum over the N points
+        dp = _mul_conj(q64.expand(-1, p64.shape[1], -1), g64).to(p4.dtype)
+        return dq, dp
+
+
 def quaternion_rotate(pc, q):
     """p' = vec(qn (0,p) qn*), qn = q/|q| with the norm NOT detached (dpc/util/quaternion.py:119-121).
     The conjugate multiplies by a float64 constant (:91-92), which is why the reference's result is fp64."""
+    p4 = F.pad(pc, (1, 0))  # (0, x, y, z)
+    if EXACT_POSE_GRADIENT and q.dtype != F64:
+        qn_ref = (q / q.norm(p=2, dim=-1, keepdim=True)).detach()           # the reference's fp32 values
+        q64 = q.to(F64)
+        qn64 = q64 / q64.norm(p=2, dim=-1, keepdim=True)                      # gradient path in fp64
+        qn = (qn64 + (qn_ref.to(F64) - qn64).detach()).unsqueeze(1)           # fp64 tensor, reference's values
+        conj = qn * torch.tensor([1.0, -1.0, -1.0, -1.0], dtype=F64)
+        return _hamilton(_FirstProductExactSum.apply(qn, p4), conj)[..., 1:4]
     qn = (q / q.norm(p=2, dim=-1, keepdim=True)).unsqueeze(1)  # [B,1,4]
     conj = qn * torch.tensor([1.0, -1.0, -1.0, -1.0], dtype=F64)
-    p4 = F.pad(pc, (1, 0))  # (0, x, y, z)
     return _hamilton(_hamilton(qn, p4), conj)[..., 1:4]
 
 

@@ -9,7 +9,14 @@ i.e. BASELINE.json's "1e-5 fp32" as an absolute bound for O(1) quantities (silho
 to the largest reference entry where the values are O(10..1000) (losses summed over 4096 pixels, gradients under the
 fixtures' synthetic weights): fp32 device results have 24 significant bits, the references are fp64.  Tighter bounds are
 used where the arithmetic allows them (bit-exact cell records and indices, 2e-6 on transformed coordinates, 1e-6 between
-two device paths); nothing is compared more loosely."""
+two device paths).
+
+The reference of every d(q) is the oracle with EXACT_POSE_GRADIENT (oracle/dpc_oracle.py): the reference's forward bit for bit,
+its gradient w.r.t. the pose quaternion with the sum over the points taken in fp64.  torch takes that sum in fp32, over a
+vector whose radial part (|.| ~ 100..1000) cancels afterwards: the reference's OWN d(q) scatters by up to the size of the rule
+around its exact value (1.6e-5 at N = 1300, |d(q)| ~ 1), so a device value can be held to the rule only against the exact sum.
+test_pose_gradient_against_the_reference_and_its_exact_sum keeps the raw reference in the picture: there the device must also
+be within the rule PLUS the reference's measured own deviation of the raw reference."""
 import json
 import os
 
@@ -36,7 +43,9 @@ def R():
 def O():
     from oracle import dpc_oracle as O
 
-    return O
+    O.EXACT_POSE_GRADIENT = True   # see the module docstring; the golden-vector tests use stored reference values, not this
+    yield O
+    O.EXACT_POSE_GRADIENT = False
 
 
 def dev(a, grad=False, dtype=torch.float32):
@@ -1478,6 +1487,45 @@ def test_step_plan_is_bit_identical_to_the_autograd_path(R, O, B, N, G, ksz, sig
                 assert torch.equal(g, w), "step plan, run %d: %s differs" % (it, name)
     with pytest.raises(ValueError):
         plan.run(sets[0][0].double(), sets[0][1], sets[0][2], sets[0][3])
+
+
+def test_pose_gradient_against_the_reference_and_its_exact_sum(R, O):
+    """The case that sat AT the parity rule in round 2 (K = reps = 8 shared sets, N = 1300, |d(q)| = 1.67): the reference's own
+    d(q) -- torch sums the per-point terms of the first Hamilton product in fp32 -- deviates from the same gradient summed
+    exactly by about the size of the rule; the device (fp64 sums from the wave totals on) is held to the rule against the
+    exact sum, and to the rule plus that measured deviation against the raw reference."""
+    K = reps = 8
+    S, N, G = 2, 1300, 32
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    pc = O.synth_inputs(S, N, G, 5100 + K)[0]
+    _, q, s, _, _, _ = O.synth_inputs(S * reps, 4, G, 5200)
+    gt = O.synth_inputs(S, 1, G, 5300)[3]
+    refs = {}
+    try:
+        for exact in (False, True):
+            O.EXACT_POSE_GRADIENT = exact
+            cp, cq, cs = (x.clone().requires_grad_(True) for x in (pc, q, s))
+            out = O.pointcloud_project_fast(cfg, cp.repeat_interleave(reps, dim=0), cq, None, None, O.smoothing_kernel(cfg, 0.9), scaling_factor=cs)
+            loss, win = O.proj_loss_pose_candidates(gt, out["proj"], K)
+            loss.backward()
+            refs[exact] = (out["proj"].detach(), cq.grad.double(), cp.grad.double(), win)
+    finally:
+        O.EXACT_POSE_GRADIENT = True
+    assert torch.equal(refs[False][0], refs[True][0]), "the exact-sum mode must not change the reference's forward"
+    own = float((refs[False][1] - refs[True][1]).abs().max())
+    scale = max(1.0, float(refs[True][1].abs().max()))
+    gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+    loss, _, win = R.pointcloud_project_loss(cfg, gp, gq, None, None, R.smoothing_kernel(cfg, 0.9), scaling_factor=gs, gt=dev(gt), num_candidates=K)
+    loss.backward()
+    assert np.array_equal(win.cpu().numpy(), refs[True][3].numpy())
+    err_exact = float((gq.grad.double().cpu() - refs[True][1]).abs().max())
+    err_raw = float((gq.grad.double().cpu() - refs[False][1]).abs().max())
+    ERRORS.append(("pose gradient: dq vs the reference's exact sum", err_exact, scale))
+    ERRORS.append(("pose gradient: the raw reference vs its own exact sum (not a device error)", own, scale))
+    assert err_exact <= TOL * scale, (err_exact, scale)
+    assert err_raw <= TOL * scale + own, (err_raw, own, scale)
+    assert own > 0.3 * TOL * scale, "the reference's fp32 summation noise was expected to be visible in this case (%.2e)" % own
+    close(gp.grad, refs[True][2], TOL, "pose gradient case: dpc")
 
 
 def test_zz_error_report():

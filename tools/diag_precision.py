@@ -26,10 +26,10 @@ def rel(a, b):
     return float((a - b).abs().max()), max(1.0, float(b.abs().max()))
 
 
-def budget(B, N, G, ksz, sig, seed):
+def budget(B, N, G, ksz, sig, seed, inputs=None):
     cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=ksz)
     kern = O.smoothing_kernel(cfg, sig)
-    pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, seed)
+    pc, q, s, gt = inputs if inputs is not None else O.synth_inputs(B, N, G, seed)[:4]
     d = torch.device("cuda")
     # ---- device
     plan = R.project_loss_step(cfg, R.smoothing_kernel(cfg, sig), B, N, d)
@@ -41,7 +41,9 @@ def budget(B, N, G, ksz, sig, seed):
 
     # ---- fp64 oracle, split at the same places
     def forward(gw_override=None):
-        cp, cq, cs = (x.clone().requires_grad_(True) for x in (pc, q, s))
+        # fp32 leaves like the reference's inputs (its first transform ops run in fp32; the gradients come back rounded to
+        # fp32 ONCE, half an ulp: compare at that resolution)
+        cp, cq, cs = (x.float().clone().requires_grad_(True) for x in (pc, q, s))
         tr = O.pc_perspective_transform(cfg, cp, cq)
         raw, _ = O.pointcloud2voxels3d_fast(cfg, tr, None)
         vox = torch.clamp(raw.unsqueeze(1), 0.0, 1.0)
@@ -92,7 +94,54 @@ def budget(B, N, G, ksz, sig, seed):
         print("  %-92s err %.3e  scale %.3g  ratio to the rule %.2f" % (name, e, sc, e / (1e-5 * sc)))
 
 
+def winners_of_the_shared_set_case():
+    """The inputs of tests/test_gpu_parity.py::test_shared_point_sets_vs_oracle[8-8-2], reduced to the two winning clouds (the
+    only ones with a backward): the case whose d(q) sits at the parity rule."""
+    K = reps = 8
+    S, N, G = 2, 1300, 32
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    pc = O.synth_inputs(S, N, G, 5100 + K)[0]
+    _, q, s, _, _, _ = O.synth_inputs(S * reps, 4, G, 5200)
+    gt = O.synth_inputs(S, 1, G, 5300)[3]
+    ref = O.pointcloud_project_fast(cfg, pc.repeat_interleave(reps, dim=0), q, None, None, O.smoothing_kernel(cfg, 0.9), scaling_factor=s)
+    _, win = O.proj_loss_pose_candidates(gt, ref["proj"], K)
+    rows = torch.arange(S) * K + win
+    print("winners", win.tolist())
+    return pc, q[rows], s[rows], gt
+
+
+def shared_set_case_both_paths():
+    """d(q) of the K = reps = 8 case through the unfused column kernels (as the test runs it) and, for its two winners alone,
+    through the fused K = 1 path -- against the same oracle gradients."""
+    K = reps = 8
+    S, N, G = 2, 1300, 32
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    pc = O.synth_inputs(S, N, G, 5100 + K)[0]
+    _, q, s, _, _, _ = O.synth_inputs(S * reps, 4, G, 5200)
+    gt = O.synth_inputs(S, 1, G, 5300)[3]
+    leaf = lambda x: x.clone().requires_grad_(True)
+    cp, cq, cs = leaf(pc), leaf(q), leaf(s)
+    ref = O.pointcloud_project_fast(cfg, cp.repeat_interleave(reps, dim=0), cq, None, None, O.smoothing_kernel(cfg, 0.9), scaling_factor=cs)
+    rloss, win = O.proj_loss_pose_candidates(gt, ref["proj"], K)
+    rloss.backward()
+    rows = torch.arange(S) * K + win
+    d = torch.device("cuda")
+    g = lambda x: x.float().to(d).clone().requires_grad_(True)
+    gp, gq, gs = g(pc), g(q), g(s)
+    loss, _, _ = R.pointcloud_project_loss(cfg, gp, gq, None, None, R.smoothing_kernel(cfg, 0.9), scaling_factor=gs, gt=gt.float().to(d), num_candidates=K)
+    loss.backward()
+    print("K=8 path: dq err %.3e dpc err %.3e (scale dq %.3g)" % (rel(gq.grad, cq.grad)[0], rel(gp.grad, cp.grad)[0], rel(gq.grad, cq.grad)[1]))
+    hp, hq, hs = g(pc), g(q[rows]), g(s[rows])
+    loss1, _, _ = R.pointcloud_project_loss(cfg, hp, hq, None, None, R.smoothing_kernel(cfg, 0.9), scaling_factor=hs, gt=gt.float().to(d), num_candidates=1)
+    loss1.backward()
+    print("K=1 on the winners: dq err %.3e dpc err %.3e" % (rel(hq.grad, cq.grad[rows])[0], rel(hp.grad, cp.grad)[0]))
+    print("loss K=8 %.9f K=1 %.9f oracle %.9f" % (float(loss), float(loss1), float(rloss)))
+    print("dq K=8", gq.grad[rows.to(d)].cpu().numpy(), "\ndq K=1", hq.grad.cpu().numpy(), "\ndq ref", cq.grad[rows].numpy())
+
+
 if __name__ == "__main__":
+    shared_set_case_both_paths()
+    budget(2, 1300, 32, 11, 0.9, 0, winners_of_the_shared_set_case())
     budget(2, 1300, 32, 11, 0.9, 5101)
     budget(3, 8000, 64, 21, 0.64, 77)
     budget(2, 4000, 64, 21, 1.0, 78)
