@@ -67,6 +67,8 @@ class TrainStep:
         self.optimizer = torch.optim.Adam(self.nets.parameters(), lr=lr, weight_decay=cfg.weight_decay,
                                           capturable=capturable, fused=bool(fused_adam))  # train_to.py:73-74
         self._graph = None
+        self._schedule = None      # dpc.render.DeviceSchedule while a graph is being captured / replayed
+        self.recaptures = 0
         self.global_step = 0
         self.grad_sync, self.sync_samples = None, (1, 1)
 
@@ -89,10 +91,14 @@ class TrainStep:
         K, V = cfg.pose_predict_num_candidates, cfg.step_size
         all_scales = out["scaling_factor"].repeat_interleave(V * K, dim=0) if cfg.pc_learn_occupancy_scaling else None
         all_points, point_index = out["points_1"], None  # [B,N,3] shared by the V*K clouds of an object, read in place
+        sched = self._schedule       # inside a captured step: this step's sigma / keep-count live in device memory
         if cfg.pc_point_dropout != 1:                     # every replica drops its own points (:254-258 after :302-306)
             keep = R.get_dropout_prob(cfg, step)
             clouds = all_points.shape[0] * V * K
-            if self.device_dropout:
+            if sched is not None:    # rows of `capacity` slots, the live count is read on the device at every replay
+                point_index = R.point_dropout_indices(clouds, all_points.shape[1], (sched.capacity + 0.5) / all_points.shape[1],
+                                                      all_points.device, n_live=sched.n_live)
+            elif self.device_dropout:
                 point_index = R.point_dropout_indices(clouds, all_points.shape[1], keep, all_points.device)
             else:  # the reference's host RNG protocol (one np.random.choice per cloud, in batch order), indices only
                 n_out = int(all_points.shape[1] * keep)
@@ -102,7 +108,7 @@ class TrainStep:
         gt = pooled_masks(masks, cfg.vox_size)
         proj_loss, proj_out, winner = R.pointcloud_project_loss(cfg, all_points, out["poses"], None, None, kernel,
                                                                 scaling_factor=all_scales, gt=gt, num_candidates=K,
-                                                                point_index=point_index)
+                                                                point_index=point_index, schedule=sched)
         total = proj_loss.double()
         if K > 1 and cfg.pose_predictor_student:
             out["student_loss"] = student_loss(out["poses"], out["pose_student"], winner, K, cfg.pose_predictor_student_loss_weight)
@@ -127,6 +133,33 @@ class TrainStep:
         self.global_step += 1
         return total.detach()
 
+    # ---- schedules under graph replay (model_pc_to.py:59-87, 171-179, 254-258: recomputed every step) ----
+    def _schedule_values(self, step):
+        """(x/y taps, z taps, live points per cloud | None) of `step`."""
+        cfg = self.cfg
+        kern = R.smoothing_kernel(cfg, R.get_smooth_sigma(cfg, step))
+        n_live = None
+        if cfg.pc_point_dropout != 1:
+            n_live = int(cfg.pc_num_points * R.get_dropout_prob(cfg, step))
+        return kern[0].reshape(-1).numpy(), kern[2].reshape(-1).numpy(), n_live
+
+    def _new_schedule(self, step):
+        """Device-resident schedule values sized for `step` and a while after it: the tap windows of this step's sigma,
+        room for half as many live points again (the keep-probability grows along the schedule)."""
+        kxy, kz, n_live = self._schedule_values(step)
+        capacity = None if n_live is None else min(self.cfg.pc_num_points, -(-int(n_live * 1.5) // 64) * 64)
+        return R.DeviceSchedule(self.device, kxy, kz, n_live=n_live, capacity=capacity)
+
+    def _follow_schedule(self, recapture):
+        """In front of a replay: write this step's values into device memory -- or, when they no longer fit what the graph
+        was captured for (sigma crossed into another tap window, the live points outgrew the rows), capture again."""
+        kxy, kz, n_live = self._schedule_values(self.global_step)
+        if not self._schedule.tight(kxy, kz, n_live):
+            recapture()
+            self.recaptures += 1
+        else:
+            self._schedule.update(kxy, kz, n_live)
+
     def capture_compute(self, images, masks, warmup=2):
         """The multi-rank variant of capture(): forward, loss and backward as ONE HIP graph whose backward accumulates
         straight into the flat buckets of `grad_sync` (every .grad is a view into them); the gradient exchange and Adam run
@@ -149,22 +182,29 @@ class TrainStep:
         torch.cuda.current_stream(self.device).wait_stream(side)
         for p in sync.params:                 # what finish() left: views into the buckets
             p.grad = sync.views[id(p)]
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            for flat in sync.flat:
-                flat.zero_()
-            total, _ = self.loss(static_images, static_masks)
-            total.backward()                  # the hooks are disarmed: gradients simply land in the buckets
-        self._graph, static_loss = graph, total.detach()
+        state = {}
+
+        def record():
+            self._schedule = self._new_schedule(self.global_step)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for flat in sync.flat:
+                    flat.zero_()
+                total, _ = self.loss(static_images, static_masks)
+                total.backward()              # the hooks are disarmed: gradients simply land in the buckets
+            self._graph, state["graph"], state["loss"] = graph, graph, total.detach()
+
+        record()
 
         def replay(new_images, new_masks):
             static_images.copy_(new_images)
             static_masks.copy_(new_masks)
-            graph.replay()
+            self._follow_schedule(record)
+            state["graph"].replay()
             sync.reduce_now(*self.sync_samples)
             self.optimizer.step()
             self.global_step += 1
-            return static_loss
+            return state["loss"]
 
         return replay
 
@@ -174,9 +214,12 @@ class TrainStep:
 
         Everything inside the step is capture-safe: the renderer enqueues on the capturing stream and never synchronises,
         allocates through torch's (graph-private) pool, draws the point dropout on the device, and the optimiser was built
-        with capturable=True.  What is frozen into the graph: the schedule values of THIS global_step (Gaussian sigma, dropout
-        keep-probability) -- recapture when they have moved noticeably -- and the shapes.  Returns replay(images, masks) ->
-        loss tensor (static memory, overwritten by the next replay)."""
+        with capturable=True.  The schedules stay step-exact: the Gaussian's tap values and the number of kept points live in
+        device memory (dpc.render.DeviceSchedule) and are rewritten by one tiny launch in front of every replay from
+        get_smooth_sigma / get_dropout_prob of the CURRENT global_step, like the reference recomputes them every step
+        (model_pc_to.py:59-87, 171-179, 254-258); the graph is captured again, automatically, only when sigma crosses into
+        another compiled tap window or the kept points outgrow the captured rows (`recaptures` counts).  Returns
+        replay(images, masks) -> loss tensor (static memory, overwritten by the next replay)."""
         if self.grad_sync is not None:
             raise RuntimeError("capture() covers the single-process step; the overlapped gradient exchange runs eagerly")
         if self.cfg.pc_point_dropout != 1 and not self.device_dropout:
@@ -191,19 +234,26 @@ class TrainStep:
             for _ in range(warmup):          # lazy initialisations (Adam state, allocator, kernel attributes) happen here
                 self(static_images, static_masks)
         torch.cuda.current_stream(self.device).wait_stream(side)
-        self.optimizer.zero_grad(set_to_none=True)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            total, _ = self.loss(static_images, static_masks)
-            total.backward()
-            self.optimizer.step()
-        self._graph, static_loss = graph, total.detach()
+        state = {}
+
+        def record():
+            self._schedule = self._new_schedule(self.global_step)
+            self.optimizer.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                total, _ = self.loss(static_images, static_masks)
+                total.backward()
+                self.optimizer.step()
+            self._graph, state["graph"], state["loss"] = graph, graph, total.detach()
+
+        record()
 
         def replay(new_images, new_masks):
             static_images.copy_(new_images)
             static_masks.copy_(new_masks)
-            graph.replay()
+            self._follow_schedule(record)
+            state["graph"].replay()
             self.global_step += 1
-            return static_loss
+            return state["loss"]
 
         return replay

@@ -199,9 +199,9 @@ def test_drc_golden(R, O, golden, tag):
     depth = R.drc_depth_projection(p, cfg)
     close(proj, g[tag + "_proj"], 2e-6, "proj")
     close(p, g[tag + "_p"], 2e-6, "probs")
-    close(depth, g[tag + "_depth"], 2e-5, "depth")  # values up to max_depth = 10
+    close(depth, g[tag + "_depth"], TOL, "depth")  # values up to max_depth = 10
     ((proj * dev(g["w1"])).sum() + (p * dev(g["w2"])).sum() + (depth * dev(g["w3"])).sum()).backward()
-    close(v.grad, g[tag + "_dv"], 2e-4, "dv (all outputs)")  # depth weights reach 10, gradients O(30)
+    close(v.grad, g[tag + "_dv"], TOL, "dv (all outputs)")  # depth weights reach 10, gradients O(30)
     v2 = dev(g[tag + "_v"], True)
     (R.drc_projection(v2, cfg)[0] * dev(g["w1"])).sum().backward()
     close(v2.grad, g[tag + "_dv_projonly"], TOL, "dv (proj only)")
@@ -264,7 +264,7 @@ def test_chain_golden(R, O, golden, name, sem):
     else:
         close(out["voxels"][:, ::4, ::4, ::4, 0], g[sem + "_voxels_sub"], TOL, "voxels (sub-sample)")
         close(out["drc_probs"][::8, :, ::4, ::4, 0], g[sem + "_drc_probs_sub"], TOL, "drc_probs (sub-sample)")
-        close(out["voxels"].double().sum((2, 3, 4)), g[sem + "_voxels_zsum"], 2e-3, "voxels per-slice sums")
+        close(out["voxels"].double().sum((2, 3, 4)), g[sem + "_voxels_zsum"], TOL, "voxels per-slice sums")
 
 
 @pytest.mark.parametrize("name", ["f6_chain_g32_tf.npz", "f6_chain_c1_s0p64.npz"])
@@ -335,7 +335,7 @@ def test_script_body_full_projection(R, O):
         out = R.pointcloud_project_fast(cfg, pc, cam, None, None, kern, scaling_factor=sc, smooth=smooth)
         for k, ref in vals[key].items():
             got = out[k].double().sum().item()
-            assert abs(got - ref) <= 2e-5 * max(1.0, abs(ref)), (key, k, got, ref)
+            assert abs(got - ref) <= TOL * max(1.0, abs(ref)), (key, k, got, ref)
 
 
 # ------------------------------------------------------------------------------------------ oracle on fresh inputs

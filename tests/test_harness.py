@@ -149,6 +149,74 @@ def test_captured_step_matches_eager(f10, keep):
 
 
 @pytest.mark.gpu
+def test_captured_step_follows_the_sigma_schedule_step_by_step(f10):
+    """The reference recomputes sigma_rel(step) and the Gaussian every step (dpc/models/model_pc_to.py:59-63, 171-179).  The
+    captured step does too: 50 replays with max_number_of_steps shrunk so that sigma runs 1.5 -> 0.4 and crosses several
+    compiled tap windows -- every replay's loss equals the eager step's of the same global_step, and the graph was captured
+    again only where a window changed."""
+    from dpc.harness import TrainStep
+    import dpc.render as R
+
+    cfg, g, state, _ = f10
+    cfg = type(cfg)(cfg)
+    cfg.update(pc_point_dropout=1.0, max_number_of_steps=60)
+    dev = torch.device("cuda")
+    images, masks = torch.from_numpy(g["images"]).to(dev), torch.from_numpy(g["masks"]).to(dev)
+
+    def make(capturable):
+        step = TrainStep(cfg, dev, lr=1e-4, device_dropout=True, capturable=capturable)
+        step.load_reference_state(state)
+        return step
+
+    eager, captured = make(False), make(True)
+    replay = captured.capture(images, masks, warmup=2)
+    for _ in range(2):
+        eager(images, masks)
+    buckets = set()
+    le, lc = [], []
+    for _ in range(50):
+        kern = R.smoothing_kernel(cfg, R.get_smooth_sigma(cfg, eager.global_step))
+        buckets.add(R.taps_bucket(kern[0]))
+        le.append(float(eager(images, masks)))
+        lc.append(float(replay(images, masks)))
+    assert captured.global_step == eager.global_step == 52
+    assert len(buckets) >= 3, buckets
+    assert captured.recaptures == len(buckets) - 1, (captured.recaptures, buckets)
+    rel = max(abs(a - b) / abs(a) for a, b in zip(le, lc))
+    assert rel <= 2e-5, (rel, le[-3:], lc[-3:])
+    # a frozen sigma would have drifted visibly: the last step's loss with the FIRST step's kernel is another number
+    frozen = make(False)
+    frozen.global_step = 2
+    assert abs(float(frozen.loss(images, masks, global_step=2)[0]) - float(frozen.loss(images, masks, global_step=51)[0])) > 1e-3 * abs(le[0])
+
+
+@pytest.mark.gpu
+def test_captured_step_follows_the_dropout_schedule(f10):
+    """... and the number of kept points (model_pc_to.py:68-87, 254-258): keep-probability 0.3 -> 1 over 40 steps, the live
+    count is read on the device at every replay, the graph is captured again when the kept points outgrow its rows."""
+    from dpc.harness import TrainStep
+    import dpc.render as R
+
+    cfg, g, state, _ = f10
+    cfg = type(cfg)(cfg)
+    cfg.update(pc_point_dropout=0.3, pc_point_dropout_scheduled=True, pc_point_dropout_start_step=0.0, pc_point_dropout_end_step=1.0,
+               max_number_of_steps=40, pc_relative_sigma=1.0, pc_relative_sigma_end=1.0)
+    dev = torch.device("cuda")
+    images, masks = torch.from_numpy(g["images"]).to(dev), torch.from_numpy(g["masks"]).to(dev)
+    step = TrainStep(cfg, dev, lr=1e-4, device_dropout=True, capturable=True)
+    step.load_reference_state(state)
+    replay = step.capture(images, masks, warmup=1)
+    live, losses = [], []
+    for _ in range(36):
+        losses.append(float(replay(images, masks)))
+        live.append(int(step._schedule.n_live.item()))
+    want = [int(cfg.pc_num_points * R.get_dropout_prob(cfg, k)) for k in range(1, 37)]
+    assert live == want, (live, want)
+    assert all(np.isfinite(losses)) and step.recaptures >= 1 and step._schedule.capacity >= want[-1]
+    assert R.check_status() == 0
+
+
+@pytest.mark.gpu
 def test_captured_compute_with_gradient_buckets_matches_eager(f10):
     """TrainStep.capture_compute (the multi-rank form: forward + backward as one HIP graph accumulating into the exchange's
     flat buckets, exchange + Adam eager) on one process -- the collectives are no-ops, everything else is what a rank runs:
