@@ -238,11 +238,20 @@ def full_step_main(args, rank, world, local):
     from dpc.harness import TrainStep, chair_unsupervised
     from dpc.render.parallel import OverlappedGradAllReduce
 
-    cfg = chair_unsupervised(pc_point_dropout=args.keep)
+    if args.config == "c4":
+        # BASELINE configs[3] as worded: "16000 pts, 128^3 grid, batch=64 data-parallel over 8 GPUs with RCCL grad all-reduce"
+        # = 8 objects per rank, one view and one pose each (8 clouds per rank), the decoder sized by the
+        # points (1024 -> 48000: 57.9 M parameters with a gradient, 232 MB exchanged), sigma = 0.01 world units
+        cfg = chair_unsupervised(pc_point_dropout=args.keep, pc_num_points=16000, vox_size=128, batch_size=8, step_size=1,
+                                 pose_predict_num_candidates=1, pose_predictor_student=False, pc_relative_sigma=1.28,
+                                 pc_relative_sigma_end=1.28)
+    else:
+        cfg = chair_unsupervised(pc_point_dropout=args.keep)
     torch.manual_seed(0)                      # same initial weights on every rank
     if args.captured_compute:
         args.captured = True
     step = TrainStep(cfg, device, device_dropout=True, capturable=args.captured and world == 1 and not args.captured_compute)
+    torch.cuda.manual_seed(4321 + rank)      # ... but every rank draws its OWN dropout subsets (device generator)
     sync = None
     if world > 1 or args.captured_compute:
         sync = OverlappedGradAllReduce(step.nets.parameters(), bucket_mb=32, overlap=not args.no_overlap)
@@ -291,9 +300,12 @@ def full_step_main(args, rank, world, local):
             "value": world * clouds * args.steps / wall, "unit": "point-clouds/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * wall / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2] (c3): per rank 8 objects x 4 views (32 images 128x128x3), K=4 pose "
-                                   "candidates -> 128 clouds x %d of 8000 pts -> 64^3, 21 taps sigma_rel 3.0, %s"
-                                   % (int(8000 * args.keep), ("whole step as one HIP graph" if world == 1 else "forward + backward as one HIP graph, exchange + Adam eager") if args.captured else "eager launches"),
+            "config": {"workload": ("BASELINE configs[3] (c4) as a full training step: per rank 8 objects x 1 view (8 images "
+                                    "128x128x3), 1 pose -> 8 clouds x %d of 16000 pts -> 128^3, 21 taps sigma_rel 1.28, %s"
+                                    if args.config == "c4" else
+                                    "BASELINE configs[2] (c3): per rank 8 objects x 4 views (32 images 128x128x3), K=4 pose "
+                                    "candidates -> 128 clouds x %d of 8000 pts -> 64^3, 21 taps sigma_rel 3.0, %s")
+                                   % (int(cfg.pc_num_points * args.keep), ("whole step as one HIP graph" if world == 1 else "forward + backward as one HIP graph, exchange + Adam eager") if args.captured else "eager launches"),
                        "parameters": sum(p.numel() for p in trainer.nets.parameters()),
                        "gradient_exchange": None if sync is None else
                        {"backend": dist.get_backend() if dist.is_initialized() else "none (one rank)", "buckets": sync.num_buckets, "bytes": sync.nbytes,
@@ -329,6 +341,9 @@ def main():
     ap.add_argument("--config", choices=sorted(CONFIGS) + ["c3"], default="c2",
                     help="BASELINE config (default c2 = the metric's); c3 = the full training step with the RCCL gradient exchange")
     ap.add_argument("--keep", type=float, default=1.0, help="c3: point keep-probability of the dropout (1.0 = all 8000 points)")
+    ap.add_argument("--full-step", action="store_true",
+                    help="c4: BASELINE configs[3] as a full training step (networks sized for 16000 points, renderer at 128^3, "
+                         "loss, backward, RCCL gradient all-reduce, Adam) instead of the renderer shard alone")
     ap.add_argument("--no-overlap", action="store_true", help="c3: all-reduce after the backward instead of inside it")
     ap.add_argument("--captured-compute", action="store_true",
                     help="c3: forward + backward as one HIP graph accumulating into the gradient buckets, exchange + Adam eager "
@@ -346,8 +361,10 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))   # this process never touches a GPU: the N ranks are its children
     global B, N_PTS, G, SIGMA_REL, K_CAND
-    if args.config != "c3":
+    if args.config != "c3" and not args.full_step:
         B, N_PTS, G, SIGMA_REL, K_CAND = CONFIGS[args.config]
+    if args.full_step and args.config != "c4":
+        raise SystemExit("--full-step is the full-training-step form of --config c4 (c3 is a full step already)")
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -359,7 +376,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path in dpc.render)")
     if not args.rehearse_on_one_gpu and torch.cuda.device_count() < world:
         raise SystemExit("--gpus %d but this node shows %d device(s)" % (world, torch.cuda.device_count()))
-    if args.config == "c3":
+    if args.config == "c3" or args.full_step:
         return full_step_main(args, rank, world, local)
     if args.rehearse_on_one_gpu:
         local = 0

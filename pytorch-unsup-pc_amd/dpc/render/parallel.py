@@ -202,6 +202,8 @@ class OverlappedGradAllReduce:
         if on_gpu:
             ev[1].record()
             self._events.append(ev)
+            if len(self._events) >= 16:
+                self._fold_events(wait=False)
         else:
             self._host_exposed += time.perf_counter() - t0
         self.steps += 1
@@ -223,12 +225,24 @@ class OverlappedGradAllReduce:
                     p.grad = self.views[id(p)]
         self._armed = False
 
+    def _fold_events(self, wait):
+        """Move finished event pairs into the running total, so that a long run holds a handful of events, not two per step.
+        wait: also wait for the newest pair (a read of the total); otherwise only pairs that are done are folded."""
+        if wait and self._events:
+            self._events[-1][1].synchronize()
+        keep = []
+        for a, b in self._events:
+            if b.query():
+                self._host_exposed += 1e-3 * a.elapsed_time(b)
+            else:
+                keep.append((a, b))
+        self._events = keep
+
     @property
     def exposed_seconds(self):
         """Total time the compute stream (GPU) or the host (CPU tensors) waited for collectives in finish()."""
-        if self._events:
-            self._events[-1][1].synchronize()
-        return self._host_exposed + 1e-3 * sum(a.elapsed_time(b) for a, b in self._events)
+        self._fold_events(wait=True)
+        return self._host_exposed
 
     def reduce_now(self, local_samples, total_samples):
         """The exchange for gradients that are ALREADY complete in the buckets (a backward that ran without the hooks, e.g.
@@ -252,6 +266,8 @@ class OverlappedGradAllReduce:
         if on_gpu:
             ev[1].record()
             self._events.append(ev)
+            if len(self._events) >= 16:
+                self._fold_events(wait=False)
         else:
             self._host_exposed += time.perf_counter() - t0
         self.steps += 1

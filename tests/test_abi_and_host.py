@@ -179,3 +179,39 @@ def test_prefer_direct_graph_launch_sets_the_runtime_flag(monkeypatch):
     assert R.prefer_direct_graph_launch() is True and os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "0"
     monkeypatch.setenv("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1")
     assert R.prefer_direct_graph_launch() is False and os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] == "1"
+
+
+def test_camera_gradient_hand_off_carries_sc1_in_the_isa():
+    """camgrad_publish (csrc/dpc_kernels.h) hands 13 doubles per slab from workgroup to workgroup inside one launch with
+    relaxed agent-scope atomics -- the form MI355X_MICROARCH.md lists as measured valid on gfx950 ONLY when every handed-off
+    byte is stored and loaded with sc1 (write-through / L2-served) and the storing wave drains its stores before the ticket
+    add.  That is a property of the generated code, so it is checked on the generated code: in the backward slab kernel of
+    the benchmark configuration the 8-byte hand-off stores and loads carry sc1, an s_waitcnt vmcnt(0) sits between the
+    stores and the returning ticket add."""
+    import re
+    import subprocess
+
+    obj = os.path.join(ROOT, "pytorch-unsup-pc_amd", "csrc", "dpc_slab_bwd.o")
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(obj) and os.path.exists(objdump)):
+        pytest.skip("needs the built object file and llvm-objdump")
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        # the device code object sits in the host object's .hip_fatbin section: dump it, unbundle, disassemble
+        subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "--dump-section", ".hip_fatbin=" + tmp + "/fb.bin", obj],
+                       check=True, capture_output=True)
+        subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--type=o", "--unbundle",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + tmp + "/fb.bin", "--output=" + tmp + "/dev.o"],
+                       check=True, capture_output=True)
+        asm = subprocess.run([objdump, "-d", tmp + "/dev.o"], check=True, capture_output=True, text=True).stdout
+    m = re.search(r"<_ZN4dpck\S*k_gather_hwILi64ELi8ELi3E\S*>:\n(.*?)\n\n", asm, re.S)
+    assert m, "k_gather_hw<64,8,3> not found in the disassembly"
+    body = m.group(1)
+    stores = [l for l in body.splitlines() if "global_store_dwordx2" in l and "sc1" in l]
+    loads = [l for l in body.splitlines() if "global_load_dwordx2" in l and "sc1" in l]
+    assert stores and len(loads) >= 8, (len(stores), len(loads))
+    lines = body.splitlines()
+    first_store = next(i for i, l in enumerate(lines) if "global_store_dwordx2" in l and "sc1" in l)
+    ticket = next(i for i, l in enumerate(lines) if i > first_store and "global_atomic_add" in l and "sc0" in l)   # returning add
+    assert any("s_waitcnt vmcnt(0)" in l for l in lines[first_store:ticket]), "no vmcnt(0) between the hand-off stores and the ticket"

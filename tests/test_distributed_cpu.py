@@ -84,7 +84,7 @@ def test_shard_ranges_cover_everything():
 # focal heads get no gradient (such tensors must be zero-filled, not skipped, or ranks disagree
 # on the bucket layout).  The renderer is replaced by the oracle on a tiny grid.
 # ------------------------------------------------------------------------------------------------------
-def _harness_problem():
+def _harness_problem(layout="c3"):
     import json
 
     from dpc.harness import StepNets, pooled_masks
@@ -95,6 +95,8 @@ def _harness_problem():
     golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     cfg = C(json.load(open(os.path.join(golden, "f10_config.json"))))
     cfg.update(batch_size=4, vox_size=8, pc_gauss_kernel_size=3)
+    if layout == "c4":   # BASELINE configs[3] as a full step: one view and one pose per object, the decoder sized by the points
+        cfg.update(step_size=1, pose_predict_num_candidates=1, pose_predictor_student=False, pc_num_points=96, batch_size=6)
     torch.manual_seed(11)
     nets = StepNets(cfg)
     g = torch.Generator().manual_seed(12)
@@ -154,13 +156,13 @@ def test_two_rank_gradients_of_the_real_networks():
 # The exchange started from autograd hooks while the backward is still running (what bench.py --config c3 runs over
 # RCCL): two steps, so that the second one goes through the adapted per-bucket arrival counts.
 # ------------------------------------------------------------------------------------------------------
-def _hooked_worker(rank, world, port, ret):
+def _hooked_worker(rank, world, port, ret, layout="c3"):
     from dpc.render.parallel import OverlappedGradAllReduce, shard_samples
 
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        cfg, nets, images, gt = _harness_problem()
+        cfg, nets, images, gt = _harness_problem(layout)
         lo, hi = shard_samples(cfg.batch_size, rank, world)
         sync = OverlappedGradAllReduce(nets.parameters(), bucket_mb=0.05)
         launched_early = []
@@ -192,5 +194,26 @@ def test_two_rank_overlapped_exchange_matches_single_process():
             g = ret[r]["grads"][k]
             if p.grad is None:
                 assert g is None, k   # the optimiser sees what the single-process run shows it
+            else:
+                assert torch.allclose(g, p.grad, rtol=1e-4, atol=1e-6 * float(p.grad.abs().max())), k
+
+
+def test_two_rank_exchange_of_the_config4_full_step_layout():
+    """BASELINE configs[3] as worded -- data-parallel objects, one cloud each, WITH the gradient all-reduce -- at a tiny
+    shape: one view and one pose candidate per object (`bench.py --config c4 --full-step` per rank: 8 objects of 16000
+    points into 128^3), 6 objects over 2 ranks, the hooked exchange against single-process gradients."""
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ret = mp.get_context("spawn").Manager().dict()
+    mp.spawn(_hooked_worker, args=(2, port, ret, "c4"), nprocs=2, join=True)
+    cfg, nets, images, gt = _harness_problem("c4")
+    assert cfg.pose_predict_num_candidates == 1 and nets.decoder.pts_raw_fc.out_features == 3 * 96
+    _harness_loss(cfg, nets, images, gt, 0, cfg.batch_size).backward()
+    for r in (0, 1):
+        for k, p in nets.named_parameters():
+            g = ret[r]["grads"][k]
+            if p.grad is None:
+                assert g is None, k
             else:
                 assert torch.allclose(g, p.grad, rtol=1e-4, atol=1e-6 * float(p.grad.abs().max())), k
