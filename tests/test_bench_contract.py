@@ -98,11 +98,11 @@ def test_measured_traffic_reads_the_committed_profile():
 
 
 def test_committed_headline_line_carries_the_contract_fields():
-    """The first line of profiles/r02_bench_lines.jsonl is `python bench.py --steps 20 --warmup 5` as the driver runs it:
+    """The first line of profiles/r03_bench_lines.jsonl is `python bench.py --steps 20 --warmup 5` as the driver runs it:
     every field of the bench contract, the roofline and CPU-baseline objects, and the launch settings that shape `value`."""
     import json
 
-    with open(os.path.join(ROOT, "profiles", "r02_bench_lines.jsonl")) as fh:
+    with open(os.path.join(ROOT, "profiles", "r03_bench_lines.jsonl")) as fh:
         rec = json.loads(fh.readline())["line"]
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -112,9 +112,29 @@ def test_committed_headline_line_carries_the_contract_fields():
     roof = rec["roofline"]
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert roof["traffic"] and roof["traffic"] > 0.9 * roof["algorithmic_bytes_per_launch"]
+    # the object names ONE kernel, chosen from a committed profile (not from this run's level event timings), and carries
+    # every kernel of the step beside it
+    assert roof["chosen_by"].startswith("profiles/") and set(roof["all_kernels"]) == set(rec["kernels_us"])
+    assert all(0 < k["frac"] <= 1 for k in roof["all_kernels"].values())
+    step = rec["roofline_step"]
+    assert 0 < step["own_traffic_frac"] < step["frac"] <= 1.0    # what the launches really move vs the contractual A(N,G)
     cpu = rec["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and "32 clouds" in cpu["sample"]
     cfg = rec["config"]
     assert "model" not in cfg and cfg["workload"].startswith("BASELINE configs[1]")
-    assert cfg["hip_graph_packet_capture"] is False and cfg["batches_in_flight"] == 1 and cfg["split"] == 1
+    # the headline is one native call per step: no HIP graph, so no runtime graph setting shapes it
+    assert "native call" in cfg["launch"] and cfg["hip_graph_packet_capture"] is None
+    assert cfg["batches_in_flight"] == 1 and cfg["split"] == 1
     assert rec["two_batches_in_flight"]["point_clouds_per_sec"] > rec["value"]   # reported beside, never as, the value
+    assert rec["hip_graph_replay"]["point_clouds_per_sec"] > 0
+
+
+def test_dominant_kernel_is_chosen_from_the_committed_profile():
+    """Two kernels of the c2 step are level (17.0 / 17.6 us) and used to swap places in the `roofline` object from run to run:
+    the choice now comes from the committed rocprofv3 summary of the config."""
+    b = _bench()
+    a, src_a = b.dominant_kernel({"k_splat_xl": 0.0180, "k_gather_hw": 0.0170, "k_locate": 0.007, "k_zcol_fwdbwd": 0.015}, "c2")
+    c, src_c = b.dominant_kernel({"k_splat_xl": 0.0170, "k_gather_hw": 0.0180, "k_locate": 0.007, "k_zcol_fwdbwd": 0.015}, "c2")
+    assert a == c and src_a == src_c and src_a.startswith("profiles/")
+    d, src_d = b.dominant_kernel({"k_unknown": 1.0, "k_other": 2.0}, "c2")
+    assert d == "k_other" and "event" in src_d
