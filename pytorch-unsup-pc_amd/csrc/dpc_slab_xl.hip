@@ -18,7 +18,11 @@ namespace dpck {
 namespace {
 
 constexpr int kXG = 64;     // H = W = 64: one wave per grid row
-constexpr int kXSeg = 16;   // y outputs per thread
+#ifndef DPC_XL_FWD_SEG
+#define DPC_XL_FWD_SEG 16
+#endif
+constexpr int kXSeg = DPC_XL_FWD_SEG;   // y outputs per thread (16: ZS x 256 threads per workgroup; 8: ZS x 512)
+constexpr int kXWavesPerPlane = kXG / kXSeg;
 
 template <int CTRL>
 __device__ inline float dpp_zero_fill(float v) {
@@ -67,12 +71,12 @@ __device__ inline float wpass_lanes(float v, const TapsT<RB>& taps) {
 //   accumulator planes carry RB zero rows above and below (the zero padding of the H pass)
 // ------------------------------------------------------------------------------------------------------
 template <int ZS, int RB>
-__global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells, TapsT<RB> taps_arg, float* __restrict__ Tbuf,
+__global__ __launch_bounds__(ZS * kXWavesPerPlane * 64) void k_splat_xl(DpcParams P, Cells cells, TapsT<RB> taps_arg, float* __restrict__ Tbuf,
                                                        uint64_t* __restrict__ mask, float* __restrict__ sse,
                                                        float* __restrict__ loss_zero, int* __restrict__ winner_zero,
                                                        unsigned long long* __restrict__ ticket_zero) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
-  constexpr int NT = ZS * 256, PR = kXG + 2 * RB, ACC = ZS * PR * kXG, WIN = kXSeg + 2 * RB;
+  constexpr int NT = ZS * kXWavesPerPlane * 64, PR = kXG + 2 * RB, ACC = ZS * PR * kXG, WIN = kXSeg + 2 * RB;
   static_assert(ACC % 4 == 0, "zero fill in 16-byte words, two halves");
   const TapsT<RB> taps = resolve_taps<RB>(taps_arg, P.dev_taps_xy, P.taps_xy, false);
   const Blk bk = block_coords(P.B);
@@ -96,6 +100,9 @@ __global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells,
   constexpr int PRE = 2, ZH = (ACC / 2) / 2;
   RecordRange rr{0, 0};
   if (flat) rr = load_record_range(cells, b, max(z0 - 1, 0), z0 + nz);
+#ifdef DPC_ABLATE
+  if (!DPC_ABL(3))
+#endif
   for (int i = tid; i < ZH; i += NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   if (flat) finish_record_table(rr, tab);
   __syncthreads();
@@ -115,6 +122,9 @@ __global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells,
     }
     npre = PRE * NT;
   }
+#ifdef DPC_ABLATE
+  if (!DPC_ABL(3))
+#endif
   for (int i = ZH + tid; i < ACC / 2; i += NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   DPC_STAMP(1);
@@ -131,6 +141,9 @@ __global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells,
         for (int e = 0; e < 2; ++e) {
           if (c.ix + e >= kXG) continue;
           const float w = c.wz[k] * c.wy[j] * c.wx[e];
+#ifdef DPC_ABLATE
+          if (!DPC_ABL(4) || w == 123.456f)
+#endif
           atomicAdd(&acc[(zz * PR + RB + c.iy + j) * kXG + c.ix + e], to_fixed(w));  // ds_add_u64
         }
       }
@@ -179,11 +192,17 @@ __global__ __launch_bounds__(ZS * 256) void k_splat_xl(DpcParams P, Cells cells,
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float h = 0.f;
+#ifdef DPC_ABLATE
+      if (DPC_ABL(6)) { o[e] = v[j + e + RB]; continue; }
+#endif
 #pragma unroll
       for (int tp = 0; tp < 2 * RB + 1; ++tp) h = fmaf(taps.w[tp], v[j + e + tp], h);
       o[e] = wpass_lanes<RB>(h, taps);
     }
     quad_transpose(o, lane);
+#ifdef DPC_ABLATE
+    if (!DPC_ABL(5) || o[0] == 123.456f)
+#endif
     *reinterpret_cast<f32x4*>(Tout + (size_t)j * kXG) = f32x4{o[0], o[1], o[2], o[3]};
   }
   DPC_STAMP(5);
@@ -198,7 +217,7 @@ int launch_splat_xl_zr(const DpcParams* p, Cells cells, const float* kxy, const 
   static LdsLimit limit;
   int rc = set_lds(kern, lds, limit);
   if (rc != DPC_OK) return rc;
-  DPC_LAUNCH("k_splat_xl", kern, dim3(((p->D + ZS - 1) / ZS) * p->B), dim3(ZS * 256), lds, st, *p, cells,
+  DPC_LAUNCH("k_splat_xl", kern, dim3(((p->D + ZS - 1) / ZS) * p->B), dim3(ZS * kXWavesPerPlane * 64), lds, st, *p, cells,
              make_taps<RB>(kxy, pxy, false), Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
   return launch_ok();
 }
