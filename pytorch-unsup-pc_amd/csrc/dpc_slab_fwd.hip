@@ -35,34 +35,38 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
   const bool present = i < P.N, live = i < n_live;
   constexpr int MW = kLocThreads / 32;  // mask words per bin
   for (int k = tid; k < nbins * MW; k += kLocThreads) member[k] = 0u;
-  // every thread normalises the quaternion itself (a dozen fp32 ops): cheaper than one thread doing it while 255 wait
-  CameraRef cam_s;
-  if (SRC == 0) cam_s = load_camera_ref(P, q, t, f, b);
-
   PointRec rec;
   rec.code = -1; rec.tz = rec.ty = rec.tx = 0.f;
   float src_pt[3] = {0.f, 0.f, 0.f};  // the untransformed point (SRC 0), carried next to its record for the backward
   int src_i = i;                      // ... and its index inside the stored point set (where its gradient goes)
+  const size_t idx = (size_t)b * P.N + (live ? i : 0);
+  bool in_set = true;
+  if (SRC == 0 && live) {
+    // the point is requested FIRST: its load (behind the index load, when there is one) is the longest latency of the
+    // kernel, and the camera below -- scalar loads of q, t, f, an fp32 normalisation -- fits under it
+    const int reps = P.point_replicas > 1 ? P.point_replicas : 1;  // replicas of one point set read the same rows
+    if (P.point_index != nullptr) {   // this cloud's own subset of the stored set
+      src_i = P.point_index[idx];
+      // an index outside the stored set never becomes an address (the reference's fancy indexing raises IndexError,
+      // point_cloud_to.py:266-295): the point is dropped -- an out-of-bounds record at source index 0, which neither the
+      // forward nor the backward touches -- and the caller's status word says so
+      in_set = (unsigned)src_i < (unsigned)P.N_src;
+      if (!in_set) {
+        src_i = 0;
+        if (P.status != nullptr) atomicOr(P.status, (int)DPC_STATUS_BAD_INDEX);
+      }
+    }
+    const float* p = static_cast<const float*>(pts) + ((size_t)(b / reps) * points_per_set(P) + src_i) * 3;
+    src_pt[0] = p[0]; src_pt[1] = p[1]; src_pt[2] = p[2];
+  }
+  // every thread normalises the quaternion itself (a dozen fp32 ops): cheaper than one thread doing it while 255 wait
+  CameraRef cam_s;
+  if (SRC == 0) cam_s = load_camera_ref(P, q, t, f, b);
+
   if (live) {
-    const size_t idx = (size_t)b * P.N + i;
     double Z, Y, X;
     if (SRC == 0) {
-      const int reps = P.point_replicas > 1 ? P.point_replicas : 1;  // replicas of one point set read the same rows
-      bool in_set = true;
-      if (P.point_index != nullptr) {   // this cloud's own subset of the stored set
-        src_i = P.point_index[idx];
-        // an index outside the stored set never becomes an address (the reference's fancy indexing raises IndexError,
-        // point_cloud_to.py:266-295): the point is dropped -- an out-of-bounds record at source index 0, which neither the
-        // forward nor the backward touches -- and the caller's status word says so
-        in_set = (unsigned)src_i < (unsigned)P.N_src;
-        if (!in_set) {
-          src_i = 0;
-          if (P.status != nullptr) atomicOr(P.status, (int)DPC_STATUS_BAD_INDEX);
-        }
-      }
-      const float* p = static_cast<const float*>(pts) + ((size_t)(b / reps) * points_per_set(P) + src_i) * 3;
-      src_pt[0] = p[0]; src_pt[1] = p[1]; src_pt[2] = p[2];
-      project_point_ref(cam_s, p[0], p[1], p[2], Z, Y, X);
+      project_point_ref(cam_s, src_pt[0], src_pt[1], src_pt[2], Z, Y, X);
       if (!in_set) Z = Y = X = 2.0;   // outside [-1/2, 1/2]^3: make_record marks it out of bounds
       if (tr_pc != nullptr) {
         tr_pc[idx * 3 + 0] = (float)Z; tr_pc[idx * 3 + 1] = (float)Y; tr_pc[idx * 3 + 2] = (float)X;
