@@ -36,11 +36,14 @@ for p in (ROOT, os.path.join(ROOT, "pytorch-unsup-pc_amd")):
         sys.path.insert(0, p)
 
 # The default step is ONE native call that enqueues the four kernels (dpc_project_loss_step): no HIP graph, no runtime
-# setting involved.  Only `--launch graph` (the round-1/2 way: the autograd path captured and replayed) asks for graph replay
+# setting involved.  Only runs whose VALUE comes from a replayed graph -- `--launch graph` (the round-1/2 way: the autograd
+# path captured and replayed) and the captured full training steps -- ask for graph replay
 # without the runtime's pre-built AQL packets ("graph packet capture", the default of ROCm 7, costs about 1 us per kernel
 # boundary inside a replayed graph on MI355X): read when HIP initialises, so set before torch is
 # imported; an explicit DEBUG_CLR_GRAPH_PACKET_CAPTURE in the environment wins.
-if "graph" in [a for i, a in enumerate(sys.argv) if i and sys.argv[i - 1] == "--launch"] or "--launch=graph" in sys.argv:
+_argv = sys.argv[1:]
+if ("graph" in [a for i, a in enumerate(_argv) if i and _argv[i - 1] == "--launch"] or "--launch=graph" in _argv
+        or "c3" in [a for i, a in enumerate(_argv) if i and _argv[i - 1] == "--config"] or "--full-step" in _argv):
     os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # = dpc.render.prefer_direct_graph_launch()
 
 import torch
@@ -461,9 +464,9 @@ def main():
 
         # the default step: forward + backward as ONE native call on static buffers (no graph, no Python between launches)
         plan = None
-        if (args.launch == "plan" and K_CAND == 1 and ns == 1 and args.api == "fused" and not args.no_graph
+        if (args.launch == "plan" and ns == 1 and args.api == "fused" and not args.no_graph
                 and args.in_flight == 1 and args.split == 1):
-            plan = R.project_loss_step(cfg, kern, B, N_PTS, device)
+            plan = R.project_loss_step(cfg, kern, B, N_PTS, device, num_candidates=K_CAND, point_replicas=B // pc.shape[0])
             plan.bind(pc.detach(), q.detach(), s.detach(), gt)
             for _ in range(3):
                 plan.run()

@@ -190,18 +190,21 @@ int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, co
                          int column_backward_done, float* dpc, float* dsmall, void* workspace, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
- * The whole step in ONE call: dpc_project_loss_fwd (one pose candidate per sample, column backward fused into the forward)
- * followed by dpc_project_loss_bwd -- four launches enqueued back to back by native code.  What a training loop calls once
+ * The whole step in ONE call: dpc_project_loss_fwd followed by dpc_project_loss_bwd -- four launches (one pose candidate per
+ * sample: the column backward is fused into the forward) or six (K candidates: locate, slab, ray march, finalize, column
+ * backward and gather of the winners) enqueued back to back by native code.  What a training loop calls once
  * per step instead of replaying a captured HIP graph of the two calls: the same kernels, the same results bit for bit, and
  * no graph (on MI355X / ROCm 7.2 the eager native sequence is 2-3 us per step FASTER than the replayed graph: 55.3 against
  * 57.2-58.2 us at B = 32, N = 8000, 64^3; host cost of the call 18 us, well under the GPU time).
- *   fwd_dsmall, dsmall, workspace, dloss: as bwd_dsmall / dsmall / workspace / dloss of the two calls above.
- * DPC_ERR_UNSUPPORTED when the column backward cannot be fused (see dpc_project_loss_fwd): use the two calls then.
+ *   num_candidates, trans, sse_tiles, fwd_dsmall, dsmall, workspace, dloss: as in the two calls above (trans and sse_tiles
+ *   are needed when the column backward is not fused into the forward, i.e. always for K > 1; may be NULL for K = 1 on the
+ *   32/64/128-deep grids).
  * ------------------------------------------------------------------------------------------------- */
 int dpc_project_loss_step(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
-                          const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt, void* cells,
-                          float* grid_wh, uint64_t* mask, float* proj, float* sse, float* loss, int32_t* winner,
-                          void* workspace, float* fwd_dsmall, const float* dloss, float* dpc, float* dsmall, void* stream);
+                          const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt,
+                          int num_candidates, void* cells, float* grid_wh, uint64_t* mask, float* proj, float* trans,
+                          float* sse, float* sse_tiles, float* loss, int32_t* winner, void* workspace, float* fwd_dsmall,
+                          const float* dloss, float* dpc, float* dsmall, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Stage-level entry points (one per reference function), used for the sub-stage API and to cross-check the

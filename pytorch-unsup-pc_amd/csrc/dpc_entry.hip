@@ -169,22 +169,17 @@ int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, co
 }
 
 int dpc_project_loss_step(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,
-                          const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt, void* cells,
-                          float* grid_wh, uint64_t* mask, float* proj, float* sse, float* loss, int32_t* winner,
-                          void* workspace, float* fwd_dsmall, const float* dloss, float* dpc, float* dsmall, void* stream) {
-  if (!p || !loss) return DPC_ERR_NULL;
-  if (p->B == 0) return hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream) == hipSuccess ? DPC_OK : DPC_ERR_LAUNCH;
-  if (!gt || !sse || !winner || !workspace || !fwd_dsmall || !dsmall) return DPC_ERR_NULL;
-  const TapPlan pz = plan_taps(host_kern_z, p->taps_z);
-  if (!can_fuse_column_backward(p, pz, 1, grid_wh, proj, gt, workspace)) return DPC_ERR_UNSUPPORTED;
-  const float inv_S = 1.0f / (float)p->B;
-  const LossArgs lf{gt, sse, nullptr, nullptr, 1, inv_S, loss, winner, 0, nullptr};
-  int rc = project_fwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, nullptr, cells, nullptr, grid_wh, nullptr, mask, proj,
-                            nullptr, lf, workspace, fwd_dsmall, (hipStream_t)stream);
-  if (rc != DPC_OK) return rc;
-  const LossArgs lb{gt, nullptr, winner, dloss, 1, inv_S, nullptr, nullptr, 1, nullptr};
-  return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, grid_wh, mask, nullptr, proj, nullptr, lb, dpc,
-                          dsmall, workspace, nullptr, (hipStream_t)stream);
+                          const float* s, const float* host_kern_xy, const float* host_kern_z, const float* gt,
+                          int num_candidates, void* cells, float* grid_wh, uint64_t* mask, float* proj, float* trans,
+                          float* sse, float* sse_tiles, float* loss, int32_t* winner, void* workspace, float* fwd_dsmall,
+                          const float* dloss, float* dpc, float* dsmall, void* stream) {
+  if (!workspace || !fwd_dsmall) return (p && p->B == 0) ? dpc_project_loss_fwd(p, pc, q, t, f, s, host_kern_xy, host_kern_z, gt, num_candidates, nullptr, cells, grid_wh, mask, proj, trans, sse, sse_tiles, loss, winner, nullptr, nullptr, nullptr, stream) : DPC_ERR_NULL;
+  int column_done = 0;
+  int rc = dpc_project_loss_fwd(p, pc, q, t, f, s, host_kern_xy, host_kern_z, gt, num_candidates, nullptr, cells, grid_wh, mask,
+                                proj, trans, sse, sse_tiles, loss, winner, workspace, fwd_dsmall, &column_done, stream);
+  if (rc != DPC_OK || p->B == 0) return rc;
+  return dpc_project_loss_bwd(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, grid_wh, mask, proj, trans, gt, num_candidates,
+                              winner, dloss, column_done, dpc, dsmall, workspace, stream);
 }
 
 int dpc_project_loss_bwd(const DpcParams* p, const float* pc, const float* q, const float* t, const float* f,

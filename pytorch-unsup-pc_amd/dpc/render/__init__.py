@@ -446,14 +446,14 @@ def pointcloud_project_loss(cfg, point_cloud, transform, predicted_translation, 
     return loss, ProjectionOutputs(proj, staged), winner
 
 
-def project_loss_step(cfg, kernel, num_clouds, num_points, device, schedule=None):
-    """A ProjectLossStep plan for pointcloud_project_loss + backward at fixed shapes (one pose candidate per sample): static
-    buffers, ONE native call per step that enqueues the four kernels -- instead of capturing the autograd path into a HIP
+def project_loss_step(cfg, kernel, num_clouds, num_points, device, schedule=None, num_candidates=1, point_replicas=1):
+    """A ProjectLossStep plan for pointcloud_project_loss + backward at fixed shapes (`num_candidates` pose candidates per
+    sample, `point_replicas` clouds per shared point set): static buffers, ONE native call per step that enqueues the four kernels -- instead of capturing the autograd path into a HIP
     graph (same kernels, same bits, 2-3 us per step faster than the replay on MI355X).  See dpc.render._ops.ProjectLossStep;
     reference call sequence: compute_projection + add_proj_loss + loss.backward() (dpc/models/model_pc_to.py:239-282, 339-385;
     dpc/run/train_to.py:122)."""
     _check_live_branches(cfg)
-    return ProjectLossStep(_geometry(cfg, kernel, schedule), num_clouds, num_points, device)
+    return ProjectLossStep(_geometry(cfg, kernel, schedule), num_clouds, num_points, device, num_candidates, point_replicas)
 
 
 def graphed_project_loss(cfg, kernel, point_cloud, transform, scaling_factor, gt, num_candidates=1):

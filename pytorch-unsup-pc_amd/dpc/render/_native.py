@@ -110,7 +110,7 @@ def lib():
         L.dpc_taps_bucket.restype = ctypes.c_int
         L.dpc_taps_bucket.argtypes = [vp, ctypes.c_int]
         L.dpc_project_loss_step.restype = ctypes.c_int
-        L.dpc_project_loss_step.argtypes = [pp] + [vp] * 21
+        L.dpc_project_loss_step.argtypes = [pp] + [vp] * 8 + [ctypes.c_int] + [vp] * 15
         if L.dpc_abi_version() != ABI_VERSION:
             raise RuntimeError("dpc.render: libdpc_render.so ABI %d, expected %d -- rebuild it (make -C %s)"
                                % (L.dpc_abi_version(), ABI_VERSION, _CSRC))

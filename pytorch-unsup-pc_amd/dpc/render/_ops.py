@@ -401,39 +401,45 @@ class ProjectLossFused(torch.autograd.Function):
 
 
 class ProjectLossStep:
-    """One training step's worth of the renderer -- pointcloud_project_loss (one pose candidate per sample) and its backward
-    -- as a PLAN: every buffer is allocated once and a call is ONE native call that enqueues the four kernels on torch's
-    current stream (dpc_project_loss_step, include/dpc_render.h).  What a loop uses instead of capturing the autograd path into
-    a HIP graph: the same kernels and bits, no Python between the launches, and on MI355X 2-3 us per step faster than the
-    replayed graph.  Gradients land in the plan's static tensors.
+    """One training step's worth of the renderer -- pointcloud_project_loss and its backward -- as a PLAN: every buffer is
+    allocated once and a call is ONE native call that enqueues the kernels on torch's current stream
+    (dpc_project_loss_step, include/dpc_render.h: four launches with one pose candidate per sample, six with K).  What a loop
+    uses instead of capturing the autograd path into a HIP graph: the same kernels and bits, no Python between the
+    launches, and on MI355X 2-3 us per step faster than the replayed graph.  Gradients land in the plan's static tensors.
 
         plan = ProjectLossStep(geom, B, N, device)           # geom: dpc.render._geometry(cfg, kernel)
-        loss = plan.run(pc, q, s, gt)                         # fp32 contiguous device tensors [B,N,3], [B,4], [B,1]|None, [B,H,W,1]
+        loss = plan.run(pc, q, s, gt)                         # fp32 contiguous device tensors [B/R,N,3], [B,4], [B,1]|None, [B/K,H,W,1]
         plan.dpc, plan.dq, plan.ds (plan.dt, plan.df)         # d loss / d input, overwritten by every run; plan.proj, plan.winner
-    """
 
-    def __init__(self, geom, B, Npts, device):
+    num_candidates = K pose candidates per sample (min-of-K loss); point_replicas = R clouds share a point set (pc is
+    [B/R,N,3], the gradient [B/R,N,3] summed over the replicas)."""
+
+    def __init__(self, geom, B, Npts, device, num_candidates=1, point_replicas=1):
         L = N.lib()
         self.geom, self.B, self.N, self.device = geom, int(B), int(Npts), torch.device(device)
+        self.K, self.R = int(num_candidates), int(point_replicas)
+        if self.K < 1 or self.B % self.K or self.R < 1 or self.B % self.R:
+            raise ValueError("%d clouds: not a multiple of %d candidates / %d replicas" % (self.B, self.K, self.R))
         dev = self.device
-        self.P = geom.params(self.B, self.N)
+        self.P = geom.params(self.B, self.N, self.R)
         P = self.P
         f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         wpp = L.dpc_mask_words_per_plane(ctypes.byref(P))
         self.cells = _new_cells(P, dev)
         self.grid_wh = f32e(self.B, geom.D, geom.H, geom.W)
         self.mask = torch.empty((self.B, geom.D, wpp), dtype=torch.int64, device=dev)
-        self.proj, self.sse = f32e(self.B, geom.H, geom.W, 1), f32e(self.B)
+        self.proj, self.trans, self.sse = f32e(self.B, geom.H, geom.W, 1), f32e(self.B, geom.H, geom.W), f32e(self.B)
+        self.sse_tiles = f32e(self.B, (geom.H * geom.W + 255) // 256)
         self.loss = torch.zeros((), dtype=torch.float32, device=dev)
-        self.winner = torch.empty((self.B,), dtype=torch.int32, device=dev)
+        self.winner = torch.empty((self.B // self.K,), dtype=torch.int32, device=dev)
         self.ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
         self.fwd_dsmall, self.dsmall = f32e(N.DPC_SMALL_COLS * self.B), f32e(N.DPC_SMALL_COLS * self.B)
-        self.dpc = f32e(self.B, self.N, 3)
+        self.dpc = torch.zeros((self.B // self.R, self.N, 3), dtype=torch.float32, device=dev)
         self.dq, self.ds = _small(self.dsmall, N.COL_DQ, 4, self.B), _small(self.dsmall, N.COL_DS, 1, self.B)
         self.dt, self.df = _small(self.dsmall, N.COL_DT, 3, self.B), _small(self.dsmall, N.COL_DF, 1, self.B)
         self._kxy, self._kz = geom.kern_ptrs()
-        self._fixed = (N.ptr(self.cells), N.ptr(self.grid_wh), N.ptr(self.mask), N.ptr(self.proj), N.ptr(self.sse), N.ptr(self.loss),
-                       N.ptr(self.winner), N.ptr(self.ws), N.ptr(self.fwd_dsmall))
+        self._fixed = (N.ptr(self.cells), N.ptr(self.grid_wh), N.ptr(self.mask), N.ptr(self.proj), N.ptr(self.trans), N.ptr(self.sse),
+                       N.ptr(self.sse_tiles), N.ptr(self.loss), N.ptr(self.winner), N.ptr(self.ws), N.ptr(self.fwd_dsmall))
         self._tail = (N.ptr(self.dpc), N.ptr(self.dsmall))
         self._fn = L.dpc_project_loss_step
         self._pref = ctypes.byref(self.P)
@@ -451,9 +457,9 @@ class ProjectLossStep:
         """Fix the input tensors (static buffers that are refilled in place): run() without arguments then skips the
         per-call checks and pointer conversions."""
         B, g = self.B, self.geom
-        self._bound = (self._pref, self._arg(pc, (B, self.N, 3), "pc"), self._arg(q, (B, 4), "q"), self._arg(t, (B, 3), "t"),
-                       self._arg(f, (B, 1), "f"), self._arg(s, (B, 1), "s"), self._kxy, self._kz,
-                       self._arg(gt, (B, g.H, g.W, 1), "gt")) + self._fixed \
+        self._bound = (self._pref, self._arg(pc, (B // self.R, self.N, 3), "pc"), self._arg(q, (B, 4), "q"),
+                       self._arg(t, (B, 3), "t"), self._arg(f, (B, 1), "f"), self._arg(s, (B, 1), "s"), self._kxy, self._kz,
+                       self._arg(gt, (B // self.K, g.H, g.W, 1), "gt"), self.K) + self._fixed \
             + (None if dloss is None else ctypes.c_void_p(dloss.data_ptr()),) + self._tail
         self._keep = (pc, q, s, gt, t, f, dloss)
         return self
@@ -462,6 +468,8 @@ class ProjectLossStep:
         """Enqueue forward + backward on torch's current stream; returns the loss tensor (static, no sync)."""
         if pc is not None:
             self.bind(pc, q, s, gt, t, f, dloss)
+        if self.R > 1:
+            self.dpc.zero_()    # the replicas ADD into the shared gradient (include/dpc_render.h, point_replicas)
         rc = self._fn(*self._bound, ctypes.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
         if rc != 0:
             N.check(rc, "dpc_project_loss_step")
