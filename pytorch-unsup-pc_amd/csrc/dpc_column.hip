@@ -11,10 +11,9 @@ namespace {
 // The unfused ray march leaves one squared-error partial per (cloud, ray tile); here they are added in tile order (so the
 // clouds' sums, the winners and the loss are the same bits on every run), the best pose candidate of every sample is
 // picked and the loss formed.  One block.
-__global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ sse_tiles, int ntile, float* __restrict__ sse,
-                                                       int S, int K, float inv_S, float* __restrict__ loss,
-                                                       int* __restrict__ winner) {
-  __shared__ float red[256 / DPC_WAVE];
+// (as a device function: k_zcol_bwd's first workgroup runs the same code when the selection is folded into the backward)
+__device__ inline void loss_finalize_block(const float* __restrict__ sse_tiles, int ntile, float* __restrict__ sse, int S, int K,
+                                           float inv_S, float* __restrict__ loss, int* __restrict__ winner, float* red) {
   // one thread per cloud adds its tiles (independent loads, tile order), then one thread per sample picks the winner
   for (int cloud = threadIdx.x; cloud < S * K; cloud += blockDim.x) {
     float v = 0.f;
@@ -41,6 +40,13 @@ __global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__
     for (int i = 0; i < 256 / DPC_WAVE; ++i) tot += red[i];
     *loss = tot * inv_S;
   }
+}
+
+__global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ sse_tiles, int ntile, float* __restrict__ sse,
+                                                       int S, int K, float inv_S, float* __restrict__ loss,
+                                                       int* __restrict__ winner) {
+  __shared__ float red[256 / DPC_WAVE];
+  loss_finalize_block(sse_tiles, ntile, sse, S, K, inv_S, loss, winner, red);
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -393,9 +399,39 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
   const int HW = P.H * P.W;
   const bool wo = winners_only(la);  // grid over samples: this workgroup works on the winning candidate of sample bk.y
   const Blk bk = block_coords(wo ? P.B / la.K : P.B);
-  const int b = wo ? bk.y * la.K + la.winner[bk.y] : bk.y, ray = bk.x * kColThreads + threadIdx.x;
+  int win = 0;
+  if (la.winner_write != nullptr) {
+    // the min-of-K selection folded into this launch: the candidates' squared errors are the ray tiles' partials added in
+    // tile order (k_loss_finalize's arithmetic); every workgroup of a sample arrives at the same winner
+    __shared__ float cand[kColThreads];
+    __shared__ float fin_red[kColThreads / DPC_WAVE];
+    __shared__ int s_win;
+    const int tid = threadIdx.x;
+    for (int k = tid; k < la.K; k += kColThreads) {
+      float v = 0.f;
+      for (int i = 0; i < la.ntile; ++i) v += la.sse_tiles[((size_t)bk.y * la.K + k) * la.ntile + i];
+      if (k < kColThreads) cand[k] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      float best = 0.f;
+      int bi = 0;
+      for (int k = 0; k < la.K; ++k) {
+        const float v = cand[k];
+        if (k == 0 || v < best) { best = v; bi = k; }
+      }
+      s_win = bi;
+    }
+    __syncthreads();
+    win = s_win;
+    if (blockIdx.x == 0)   // ... and ONE workgroup leaves sse, winner and the loss behind, bit for bit what the separate launch would
+      loss_finalize_block(la.sse_tiles, la.ntile, la.sse, bk.ny, la.K, la.inv_S, la.loss_write, la.winner_write, fin_red);
+  } else if (wo) {
+    win = la.winner[bk.y];
+  }
+  const int b = wo ? bk.y * la.K + win : bk.y, ray = bk.x * kColThreads + threadIdx.x;
   float ds_acc = 0.f;
-  if (ray < HW && !cloud_loses(la, b)) {
+  if (ray < HW && (wo || !cloud_loses(la, b))) {
     const RayConst rc = ray_const(rh, s, b);
     float c[DD], d[DD];
     const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Tin + (size_t)b * DD * HW), 0, DD * HW * 4, 0x00020000);

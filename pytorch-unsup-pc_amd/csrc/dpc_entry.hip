@@ -174,6 +174,21 @@ int dpc_project_loss_step(const DpcParams* p, const float* pc, const float* q, c
                           float* sse, float* sse_tiles, float* loss, int32_t* winner, void* workspace, float* fwd_dsmall,
                           const float* dloss, float* dpc, float* dsmall, void* stream) {
   if (!workspace || !fwd_dsmall) return (p && p->B == 0) ? dpc_project_loss_fwd(p, pc, q, t, f, s, host_kern_xy, host_kern_z, gt, num_candidates, nullptr, cells, grid_wh, mask, proj, trans, sse, sse_tiles, loss, winner, nullptr, nullptr, nullptr, stream) : DPC_ERR_NULL;
+  const int K = num_candidates;
+  // K candidates, a column depth and a z kernel the specialised column backward covers: the min-of-K selection rides in
+  // that launch (k_zcol_bwd) instead of taking one of its own between forward and backward
+  if (p && K > 1 && K <= kColThreads && p->B > 0 && p->B % K == 0 && gt && sse && sse_tiles && loss && winner &&
+      (p->D == 32 || p->D == 64 || p->D == 128) && plan_taps(host_kern_z, p->taps_z).bucket >= 0) {
+    const int S = p->B / K;
+    const float inv_S = 1.0f / (float)S;
+    const LossArgs lf{gt, sse, nullptr, nullptr, K, inv_S, nullptr, nullptr, 0, sse_tiles, nullptr, nullptr, 0};
+    int rc = project_fwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, nullptr, cells, nullptr, grid_wh, nullptr, mask, proj,
+                              trans, lf, nullptr, nullptr, (hipStream_t)stream);
+    if (rc != DPC_OK) return rc;
+    const LossArgs lb{gt, sse, winner, dloss, K, inv_S, nullptr, nullptr, 0, sse_tiles, winner, loss, col_tiles(p)};
+    return project_bwd_impl(p, pc, q, t, f, s, host_kern_xy, host_kern_z, cells, grid_wh, mask, nullptr, proj, trans, lb, dpc,
+                            dsmall, workspace, nullptr, (hipStream_t)stream);
+  }
   int column_done = 0;
   int rc = dpc_project_loss_fwd(p, pc, q, t, f, s, host_kern_xy, host_kern_z, gt, num_candidates, nullptr, cells, grid_wh, mask,
                                 proj, trans, sse, sse_tiles, loss, winner, workspace, fwd_dsmall, &column_done, stream);

@@ -569,6 +569,12 @@ struct LossArgs {
   int* winner_out;      // forward, K == 1 only: zero-filled by k_splat_hw
   int scale_in_gather;  // backward: dT was produced by the forward for dloss = 1; k_gather_hw multiplies by *dloss
   float* sse_tiles;     // forward, unfused ray march: [B, tiles] per-tile squared errors, summed in tile order by k_loss_finalize
+  // backward of the one-call step with K > 1 (dpc_project_loss_step): the min-of-K selection is made HERE instead of by a
+  // launch of its own -- every workgroup of k_zcol_bwd picks its sample's winner from sse_tiles, workgroup 0 also writes
+  // sse, winner and the loss with k_loss_finalize's own code (same bits)
+  int* winner_write;    // [S] | nullptr
+  float* loss_write;    // [1]
+  int ntile;            // ray tiles per cloud in sse_tiles
 };
 
 // ------------------------------------------------------------------------------------------------------
@@ -709,7 +715,7 @@ __device__ inline bool cloud_loses(const LossArgs& la, int b) {
 // then (parts per cloud) x (SAMPLES) and a workgroup looks its cloud up -- launching a (1024-thread, 157 KB LDS)
 // workgroup per losing cloud just to let it return kept the winners' workgroups waiting for a CU (c5: 26 -> 15 us).
 __host__ __device__ inline bool winners_only(const LossArgs& la) {
-  return la.gt != nullptr && la.winner != nullptr && la.K > 1;
+  return la.gt != nullptr && (la.winner != nullptr || la.winner_write != nullptr) && la.K > 1;
 }
 
 // ------------------------------------------------------------------------------------------------------
