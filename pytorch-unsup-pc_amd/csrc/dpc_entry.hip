@@ -85,7 +85,7 @@ int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const 
   // backward; its per-cloud sum-and-count words live behind the ds partials and are zeroed by the slab kernel
   const bool fuse_bwd = bwd_workspace != nullptr && bwd_dsmall != nullptr && la.loss_direct != nullptr &&
                         can_fuse_column_backward(p, pz, la.K, Tbuf, proj, la.gt, bwd_workspace);
-  Workspace w{nullptr, nullptr, nullptr, nullptr, nullptr};
+  Workspace w{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   if (fuse_bwd) w = workspace_view(p, bwd_workspace);
   float* ds_part = w.ds_part;
   unsigned long long* tickets = w.tickets;  // B per-cloud words + 1 batch word behind the ds partials, 8-byte aligned
@@ -117,7 +117,7 @@ int project_bwd_impl(const DpcParams* p, const float* pc, const float* q, const 
       (rc = launch_zcol_bwd(p, host_kern_z, pz, grid_wh, s, dproj, proj, trans, w.dT, w.ds_part, dsmall, w.cg_count, dgrid_wh, la, st)) != DPC_OK)
     return rc;
   return launch_gather(pxy.bucket, p, cells_view(p, cells), pc, q, t, f, host_kern_xy, pxy, w.dT, mask, w.ds_part, ntile, dpc,
-                       dsmall, w.cg_part, w.cg_count, la, st);
+                       dsmall, w.cg_part, w.cg_count, la, st, w.dpc_fixed);
 }
 
 const LossArgs kNoLoss{nullptr, nullptr, nullptr, nullptr, 1, 1.0f, nullptr, nullptr, 0, nullptr};

@@ -721,6 +721,7 @@ __host__ __device__ inline bool winners_only(const LossArgs& la) {
 // ------------------------------------------------------------------------------------------------------
 // Backward workspace (dpc_workspace_bytes): [dT grid][ds partials B x ntile][sum-and-count words B + 1]
 //                                           [camera-gradient partials B x D x 16 doubles][arrival counters B]
+//                                           [64-bit fixed-point d(point set) sums, shared point sets only]
 // ------------------------------------------------------------------------------------------------------
 struct Workspace {
   float* dT;
@@ -728,15 +729,28 @@ struct Workspace {
   unsigned long long* tickets;   // k_zcol_fwdbwd: per-cloud squared-error words + the batch word
   double* cg_part;               // k_gather_hw: per-slab sums of the 13 camera-gradient accumulators
   unsigned int* cg_count;        // k_gather_hw: slabs of a cloud that have published (zeroed by the column kernels)
+  unsigned long long* dpc_fixed; // [B/R, N_set, 3]: where several clouds add into one point set's gradient they add 64-bit
+                                 // fixed point (2^-40): integer adds commute, so the sum is the same bits whatever order the
+                                 // clouds arrive in (float atomics made the last bits vary from run to run); nullptr otherwise
 };
+
+// d(point) contributions of clouds that share a point set, as 64-bit fixed point: |sum| < 2^23, resolution 2^-40 (9e-13)
+constexpr double kGradFixScale = 1099511627776.0;          // 2^40
+constexpr double kGradFixInv = 1.0 / 1099511627776.0;
+__device__ inline unsigned long long grad_to_fixed(float v) { return (unsigned long long)(long long)__double2ll_rn((double)v * kGradFixScale); }
 inline size_t ws_round(size_t n) { return (n + 255) / 256 * 256; }
 inline size_t ws_grid_bytes(const DpcParams* p) { return ws_round((size_t)p->B * p->D * p->H * p->W * sizeof(float)); }
 inline size_t ws_parts_bytes(const DpcParams* p) {
   return ws_round((size_t)p->B * col_tiles(p) * sizeof(float) + ((size_t)p->B + 1) * 8 + 8);
 }
 inline size_t ws_camgrad_bytes(const DpcParams* p) { return ws_round((size_t)p->B * p->D * 16 * sizeof(double)); }
+inline bool shares_points(const DpcParams* p) { return p->point_replicas > 1 || p->point_index != nullptr; }
+inline size_t ws_dpcfix_bytes(const DpcParams* p) {
+  const int reps = p->point_replicas > 1 ? p->point_replicas : 1;
+  return shares_points(p) ? ws_round((size_t)(p->B / reps) * points_per_set(*p) * 3 * sizeof(unsigned long long)) : 0;
+}
 inline size_t ws_total_bytes(const DpcParams* p) {
-  return ws_grid_bytes(p) + ws_parts_bytes(p) + ws_camgrad_bytes(p) + ws_round((size_t)p->B * sizeof(unsigned int));
+  return ws_grid_bytes(p) + ws_parts_bytes(p) + ws_camgrad_bytes(p) + ws_round((size_t)p->B * sizeof(unsigned int)) + ws_dpcfix_bytes(p);
 }
 inline Workspace workspace_view(const DpcParams* p, void* ws) {
   Workspace w;
@@ -747,6 +761,9 @@ inline Workspace workspace_view(const DpcParams* p, void* ws) {
       (reinterpret_cast<uintptr_t>(w.ds_part + (size_t)p->B * col_tiles(p)) + 7u) & ~(uintptr_t)7u);
   w.cg_part = reinterpret_cast<double*>(base + ws_grid_bytes(p) + ws_parts_bytes(p));
   w.cg_count = reinterpret_cast<unsigned int*>(base + ws_grid_bytes(p) + ws_parts_bytes(p) + ws_camgrad_bytes(p));
+  w.dpc_fixed = shares_points(p) ? reinterpret_cast<unsigned long long*>(base + ws_grid_bytes(p) + ws_parts_bytes(p) +
+                                                                          ws_camgrad_bytes(p) + ws_round((size_t)p->B * sizeof(unsigned int)))
+                                 : nullptr;
   return w;
 }
 
@@ -811,7 +828,8 @@ int launch_splat(int bucket, const DpcParams* p, Cells cells, const float* kxy, 
                  uint64_t* mask, float* sse, float* loss_zero, int* winner_zero, unsigned long long* ticket_zero, hipStream_t st);
 int launch_gather(int bucket, const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
                   const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part, int ntile,
-                  float* dpc, float* dsmall, double* cg_part, unsigned int* cg_count, const LossArgs& la, hipStream_t st);
+                  float* dpc, float* dsmall, double* cg_part, unsigned int* cg_count, const LossArgs& la, hipStream_t st,
+                  unsigned long long* dpc_fixed = nullptr);
 int launch_zcol_fwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* Tbuf, const float* s,
                     float* smoothed, float* proj, float* trans, const LossArgs& la, hipStream_t st);
 int launch_zcol_fwdbwd(const DpcParams* p, const float* host_kern_z, const TapPlan& pz, const float* Tbuf, const float* s,

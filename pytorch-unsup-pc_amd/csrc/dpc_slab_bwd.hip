@@ -20,7 +20,8 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
                                                             const float* __restrict__ ds_part, int n_ds_part,
                                                             float* __restrict__ dpc, float* __restrict__ dsmall,
                                                             double* __restrict__ cg_part,
-                                                            unsigned int* __restrict__ cg_count, LossArgs la) {
+                                                            unsigned int* __restrict__ cg_count, LossArgs la,
+                                                            unsigned long long* __restrict__ dpc_fixed) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
   const TapsT<RB> taps_adj = resolve_taps<RB>(taps_arg, P.dev_taps_xy, P.taps_xy, true);
   const int D = P.D, H = P.H, W = P.W, HW = H * W;
@@ -224,7 +225,10 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     float dpx, dpy, dpz;
     project_point_bwd(cam, o, px, py, pz, dgz * (float)(D - 1), dgy * (float)(H - 1), dgx * (float)(W - 1), dpx, dpy, dpz, g);
     if (shared_points && !single_writer) {
-      atomicAdd(dcloud + 3 * i + 0, dpx); atomicAdd(dcloud + 3 * i + 1, dpy); atomicAdd(dcloud + 3 * i + 2, dpz);
+      // several clouds add into this point set's gradient: 64-bit fixed-point adds (exact, so the sum does not depend on
+      // who arrives first); k_fixed_to_dpc turns the sums into floats behind this launch
+      unsigned long long* acc = dpc_fixed + ((size_t)(b / reps) * Nset + i) * 3;
+      atomicAdd(acc + 0, grad_to_fixed(dpx)); atomicAdd(acc + 1, grad_to_fixed(dpy)); atomicAdd(acc + 2, grad_to_fixed(dpz));
     } else {
       dcloud[3 * i + 0] = dpx; dcloud[3 * i + 1] = dpy; dcloud[3 * i + 2] = dpz;
     }
@@ -289,11 +293,25 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   DPC_STAMP(13);
 }
 
+// d(point sets) += the fixed-point sums the gather left (shared point sets with several writers)
+__global__ __launch_bounds__(256) void k_fixed_to_dpc(const unsigned long long* __restrict__ acc, float* __restrict__ dpc, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    dpc[i] += (float)((double)(long long)acc[i] * kGradFixInv);
+}
+
+// several clouds write into one point set's gradient (the kernel's own test, see k_gather_hw)
+bool fixed_point_gradients(const DpcParams* p, const LossArgs& la) {
+  const bool shared = p->point_replicas > 1 || p->point_index != nullptr;
+  const int reps = p->point_replicas > 1 ? p->point_replicas : 1;
+  const bool single_writer = winners_only(la) && shared && reps == la.K && p->point_index == nullptr;
+  return shared && !single_writer;
+}
+
 template <int GS, int ZS, int RB>
 int launch_gather_fast(const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
                        const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask,
                        const float* ds_part, int ntile, float* dpc, float* dsmall, double* cg_part, unsigned int* cg_count,
-                       const LossArgs& la, hipStream_t st) {
+                       const LossArgs& la, hipStream_t st, unsigned long long* dpc_fixed) {
   using Geo = BwdGeo<GS, RB, ZS + 1>;
   // slab + scratch tail: reduction floats, record table, staged mask words
   constexpr size_t lds = (((Geo::slab_floats(ZS + 1) + 3) / 4) * 4 + kRedMask + (ZS + 1) * GS * (GS / 32)) * sizeof(float);
@@ -312,7 +330,7 @@ int launch_gather_fast(const DpcParams* p, Cells cells, const float* pc, const f
       if (p->D % c == 0 && (size_t)(p->D / c) * clouds >= (size_t)kNumCUs) roll = c;
   const int nslab = (p->D + ZS - 1) / ZS;
   DPC_LAUNCH("k_gather_hw", kern, dim3(((nslab + roll - 1) / roll) * clouds), dim3(Geo::NT), lds, st, *p, cells, pc, q, t, f,
-             make_taps<RB>(kxy, pxy, true), ZS == 1 ? roll : ZS, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la);
+             make_taps<RB>(kxy, pxy, true), ZS == 1 ? roll : ZS, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, dpc_fixed);
   return launch_ok();
 }
 
@@ -320,16 +338,16 @@ template <int RB>
 int launch_gather_rb(const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
                   const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part,
                   int ntile, float* dpc, float* dsmall, double* cg_part, unsigned int* cg_count, const LossArgs& la,
-                  hipStream_t st) {
+                  hipStream_t st, unsigned long long* dpc_fixed) {
   if (p->H == p->W) {
     if constexpr (RB <= 4) {
-      if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
-      if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
-      if (p->H == 64) return launch_gather_fast<64, kBwdZs64, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
+      if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
+      if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
+      if (p->H == 64) return launch_gather_fast<64, kBwdZs64, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
     } else if constexpr (RB <= 10) {
-      if (p->H == 64) return launch_gather_fast<64, 7, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
-      if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);  // c4: sigma_rel 1.28 -> radius 8
-      if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st);
+      if (p->H == 64) return launch_gather_fast<64, 7, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
+      if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);  // c4: sigma_rel 1.28 -> radius 8
+      if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
     }
   }
   const int fit = planes_fit(p);
@@ -342,7 +360,7 @@ int launch_gather_rb(const DpcParams* p, Cells cells, const float* pc, const flo
   if (rc != DPC_OK) return rc;
   const bool wo = winners_only(la) && (p->point_replicas > 1 || p->point_index != nullptr);  // the kernel's own test
   DPC_LAUNCH("k_gather_hw", kern, dim3(((p->D + Zs - 1) / Zs) * (wo ? p->B / la.K : p->B)), dim3(slab_threads(p)), lds, st, *p, cells, pc, q, t, f,
-             make_taps<RB>(kxy, pxy, true), Zs, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la);
+             make_taps<RB>(kxy, pxy, true), Zs, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, dpc_fixed);
   return launch_ok();
 }
 
@@ -350,12 +368,22 @@ int launch_gather_rb(const DpcParams* p, Cells cells, const float* pc, const flo
 
 int launch_gather(int bucket, const DpcParams* p, Cells cells, const float* pc, const float* q, const float* t, const float* f,
                   const float* kxy, const TapPlan& pxy, const float* dT, const uint64_t* mask, const float* ds_part, int ntile,
-                  float* dpc, float* dsmall, double* cg_part, unsigned int* cg_count, const LossArgs& la, hipStream_t st) {
+                  float* dpc, float* dsmall, double* cg_part, unsigned int* cg_count, const LossArgs& la, hipStream_t st,
+                  unsigned long long* dpc_fixed) {
+  const bool fixed = fixed_point_gradients(p, la) && p->N > 0;
+  const int reps = p->point_replicas > 1 ? p->point_replicas : 1;
+  const size_t nfix = (size_t)(p->B / reps) * points_per_set(*p) * 3;
+  if (fixed) {
+    if (dpc_fixed == nullptr) return DPC_ERR_NULL;
+    if (hipMemsetAsync(dpc_fixed, 0, nfix * sizeof(unsigned long long), st) != hipSuccess) return DPC_ERR_LAUNCH;
+  }
   int rc = DPC_OK;
-#define DPC_GATHER(RB) rc = launch_gather_rb<RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st)
+#define DPC_GATHER(RB) rc = launch_gather_rb<RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed)
   DPC_FOR_BUCKET(bucket, DPC_GATHER)
 #undef DPC_GATHER
-  return rc;
+  if (rc != DPC_OK || !fixed) return rc;
+  DPC_LAUNCH("k_fixed_to_dpc", k_fixed_to_dpc, dim3((unsigned)std::min<size_t>((nfix + 255) / 256, 2048)), dim3(256), 0, st, dpc_fixed, dpc, nfix);
+  return launch_ok();
 }
 
 }  // namespace dpck
