@@ -150,7 +150,7 @@ int dpc_project_loss_fwd(const DpcParams* p, const float* pc, const float* q, co
   if (!p || !loss) return DPC_ERR_NULL;
   if (num_candidates < 1 || p->B % num_candidates != 0) return DPC_ERR_SHAPE;
   if (p->B == 0)   // no clouds (an empty shard): the loss of nothing is 0
-    return hipMemsetAsync(loss, 0, sizeof(float), (hipStream_t)stream) == hipSuccess ? DPC_OK : DPC_ERR_LAUNCH;
+    return zero_words_async(loss, 1, (hipStream_t)stream) ? DPC_OK : DPC_ERR_LAUNCH;
   if (!gt || !sse || !winner) return DPC_ERR_NULL;
   const int S = p->B / num_candidates;
   // one candidate per sample AND a backward workspace: the fused ray march sums the loss itself (64-bit fixed point)

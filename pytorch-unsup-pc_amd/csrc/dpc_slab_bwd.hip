@@ -375,7 +375,7 @@ int launch_gather(int bucket, const DpcParams* p, Cells cells, const float* pc, 
   const size_t nfix = (size_t)(p->B / reps) * points_per_set(*p) * 3;
   if (fixed) {
     if (dpc_fixed == nullptr) return DPC_ERR_NULL;
-    if (hipMemsetAsync(dpc_fixed, 0, nfix * sizeof(unsigned long long), st) != hipSuccess) return DPC_ERR_LAUNCH;
+    if (!zero_words_async(dpc_fixed, 2 * nfix, st)) return DPC_ERR_LAUNCH;   // a kernel, not a memset node (dpc_common.h)
   }
   int rc = DPC_OK;
 #define DPC_GATHER(RB) rc = launch_gather_rb<RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed)

@@ -404,7 +404,7 @@ int dpc_transform_bwd(const DpcParams* p, const float* pc, const float* q, const
   if (rc != DPC_OK) return rc;
   if (!pc || !q || !dout || !dpc || !dsmall) return DPC_ERR_NULL;
   if (p->B == 0) return DPC_OK;
-  if (hipMemsetAsync(dsmall, 0, (size_t)p->B * DPC_SMALL_COLS * sizeof(float), (hipStream_t)stream) != hipSuccess)
+  if (!zero_words_async(dsmall, (size_t)p->B * DPC_SMALL_COLS, (hipStream_t)stream))
     return DPC_ERR_LAUNCH;
   if (p->N == 0) return DPC_OK;
   hipLaunchKernelGGL(k_transform_bwd, dim3(p->B), dim3(kThreads), 0, (hipStream_t)stream, *p, pc, q, t, f, dout, dpc, dsmall);
