@@ -71,7 +71,8 @@ __device__ inline float wpass_lanes(float v, const TapsT<RB>& taps) {
 //   accumulator planes carry RB zero rows above and below (the zero padding of the H pass)
 // ------------------------------------------------------------------------------------------------------
 template <int ZS, int RB>
-__global__ __launch_bounds__(ZS * kXWavesPerPlane * 64) void k_splat_xl(DpcParams P, Cells cells, TapsT<RB> taps_arg, float* __restrict__ Tbuf,
+__global__ __launch_bounds__(ZS * kXWavesPerPlane * 64) void k_splat_xl(DpcParams P, Cells cells, TapsT<RB> taps_arg, int nround,
+                                                       float* __restrict__ Tbuf,
                                                        uint64_t* __restrict__ mask, float* __restrict__ sse,
                                                        float* __restrict__ loss_zero, int* __restrict__ winner_zero,
                                                        unsigned long long* __restrict__ ticket_zero) {
@@ -88,122 +89,163 @@ __global__ __launch_bounds__(ZS * kXWavesPerPlane * 64) void k_splat_xl(DpcParam
     if (loss_zero != nullptr && bk.y == 0) *loss_zero = 0.f;
   }
   const int D = P.D;
-  const int b = bk.y, z0 = bk.x * ZS;
-  const int nz = min(ZS, D - z0);
+  const int b = bk.y;
   const int tid = threadIdx.x;
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(slab);
   f32x4* s4 = reinterpret_cast<f32x4*>(slab);
   int* tab = reinterpret_cast<int*>(acc + ACC);
   const bool flat = cells.nblk <= DPC_WAVE;
-  DPC_STAMP(0);
-  // offsets | zero A | table | barrier | records -> registers | zero B | barrier | atomics  (see k_splat_hw)
-  constexpr int PRE = 2, ZH = (ACC / 2) / 2;
-  RecordRange rr{0, 0};
-  if (flat) rr = load_record_range(cells, b, max(z0 - 1, 0), z0 + nz);
-#ifdef DPC_ABLATE
-  if (!DPC_ABL(3))
-#endif
-  for (int i = tid; i < ZH; i += NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (flat) finish_record_table(rr, tab);
-  __syncthreads();
-  PointRec pre[PRE];
-  int npre = 0;
-  if (flat) {
-    const int total = tab[DPC_WAVE];
-#pragma unroll
-    for (int r = 0; r < PRE; ++r) {
-      const int j = tid + r * NT;
-      pre[r].code = -1; pre[r].tz = pre[r].ty = pre[r].tx = 0.f;
-      if (j < total) {
-        int c, pos;
-        flat_lookup(tab, j, c, pos);
-        pre[r] = load_record(cells.recs(b, c), pos);
-      }
-    }
-    npre = PRE * NT;
-  }
-#ifdef DPC_ABLATE
-  if (!DPC_ABL(3))
-#endif
-  for (int i = ZH + tid; i < ACC / 2; i += NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  __syncthreads();
-  DPC_STAMP(1);
-  auto scatter = [&](const PointRec& rec, const int4*) {
-    const Cell c = cell_from_record(rec);
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int zz = c.iz + k - z0;
-      if (zz < 0 || zz >= nz) continue;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        if (c.iy + j >= kXG) continue;
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          if (c.ix + e >= kXG) continue;
-          const float w = c.wz[k] * c.wy[j] * c.wx[e];
-#ifdef DPC_ABLATE
-          if (!DPC_ABL(4) || w == 123.456f)
-#endif
-          atomicAdd(&acc[(zz * PR + RB + c.iy + j) * kXG + c.ix + e], to_fixed(w));  // ds_add_u64
-        }
-      }
-    }
-  };
-  if (flat) {
-#pragma unroll
-    for (int r = 0; r < PRE; ++r)
-      if (pre[r].code >= 0) scatter(pre[r], nullptr);
-    for_each_record_flat(cells, b, tab, scatter, npre);
-  } else {
-    for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, scatter);
-  }
-  __syncthreads();
-  DPC_STAMP(2);
-
   // wave = (plane zz, rows y0 .. y0+15), lane = x
   const int lane = tid & (DPC_WAVE - 1);
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int zz = w % ZS, y0 = (w / ZS) * kXSeg;
-  if (zz >= nz) return;
-  const unsigned long long* col = acc + ((size_t)zz * PR + y0) * kXG + lane;  // window row i = grid row y0 + i - RB
-  unsigned long long a[WIN];
-#pragma unroll
-  for (int i = 0; i < WIN; ++i) a[i] = col[i * kXG];
-  // clamp mask: bit x of word y <=> raw <= 1 (raw >= 0 always); 64 lanes = the 64 bits of the row's word.  Lane j keeps
-  // row j's word: the 16 words of this wave leave in one 128-byte store.
-  unsigned long long* mask_out = reinterpret_cast<unsigned long long*>(mask) + ((size_t)b * D + z0 + zz) * kXG + y0;
-  unsigned long long mword = 0ull;
-#pragma unroll
-  for (int j = 0; j < kXSeg; ++j) {
-    const unsigned long long bits = __ballot(a[RB + j] <= kFixOne);
-    mword = lane == j ? bits : mword;
-  }
-  if (lane < kXSeg) mask_out[lane] = mword;
-  float v[WIN];
-#pragma unroll
-  for (int i = 0; i < WIN; ++i) v[i] = fminf(from_fixed(a[i]), 1.0f);
-  DPC_STAMP(3);
-  // four rows at a time: H pass in registers, W pass across the lanes, then the quad transpose so that every lane stores
-  // 16 contiguous bytes (lane 4q+e: row j+e, x = 4q .. 4q+3)
-  float* Tout = Tbuf + (((size_t)b * D + z0 + zz) * kXG + y0 + (lane & 3)) * kXG + (lane & ~3);
-#pragma unroll
-  for (int j = 0; j < kXSeg; j += 4) {
-    float o[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float h = 0.f;
+  // The workgroup STAYS for `nround` slabs of its cloud (slabs bk.x, bk.x + nx, ...: the launcher picks nround so that the
+  // grid is still one workgroup per CU).  A workgroup that ends is only replaced when its stores have drained -- with every
+  // CU storing its planes at the same moment that is 3 us of an empty CU per round (stamps, profiles/r03_overlap_experiments
+  // item 6); a workgroup that goes on zero-fills and scatters the next slab under the stores of this one.
+  constexpr int PRE = 2, ZH = (ACC / 2) / 2;
+  const int slab0 = bk.x, slab_step = bk.nx;
+  const int nslab = (D + ZS - 1) / ZS;
+  // offsets | zero A | table | barrier | records -> registers | zero B | barrier | atomics  (see k_splat_hw)
+  // (Holding a slab's stores back in registers until the next slab's record loads are out -- a wave's vector memory
+  // operations complete in order, so those loads are waited for together with the stores in front of them -- measured
+  // slower: 21.4 against 19.3 us; the write stream is the scarce resource and wants to start as early as it can.)
+  DPC_STAMP(0);
+  PointRec pre[PRE];
+  int npre = 0;
+  auto open_slab = [&](int sl) {   // record offsets on their way, first half of the accumulators zeroed
+    const int z0 = sl * ZS;
+    RecordRange rr{0, 0};
+    if (flat) rr = load_record_range(cells, b, max(z0 - 1, 0), z0 + min(ZS, D - z0));
 #ifdef DPC_ABLATE
-      if (DPC_ABL(6)) { o[e] = v[j + e + RB]; continue; }
+    if (!DPC_ABL(3))
 #endif
+    for (int i = tid; i < ZH; i += NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    return rr;
+  };
+  auto request_records = [&](const RecordRange& rr) {   // table, then every thread's first records into registers
+    if (flat) finish_record_table(rr, tab);
+    __syncthreads();
+    npre = 0;
+    if (flat) {
+      const int total = tab[DPC_WAVE];
 #pragma unroll
-      for (int tp = 0; tp < 2 * RB + 1; ++tp) h = fmaf(taps.w[tp], v[j + e + tp], h);
-      o[e] = wpass_lanes<RB>(h, taps);
+      for (int r = 0; r < PRE; ++r) {
+        const int j = tid + r * NT;
+        pre[r].code = -1; pre[r].tz = pre[r].ty = pre[r].tx = 0.f;
+        if (j < total) {
+          int c, pos;
+          flat_lookup(tab, j, c, pos);
+          pre[r] = load_record(cells.recs(b, c), pos);
+        }
+      }
+      npre = PRE * NT;
     }
-    quad_transpose(o, lane);
+  };
+  auto zero_rest = [&]() {
 #ifdef DPC_ABLATE
-    if (!DPC_ABL(5) || o[0] == 123.456f)
+    if (!DPC_ABL(3))
 #endif
-    *reinterpret_cast<f32x4*>(Tout + (size_t)j * kXG) = f32x4{o[0], o[1], o[2], o[3]};
+    for (int i = ZH + tid; i < ACC / 2; i += NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+  };
+  if (slab0 < nslab) {
+    const RecordRange rr = open_slab(slab0);
+    request_records(rr);
+    zero_rest();
+  }
+  DPC_STAMP(1);
+  for (int round = 0; round < nround; ++round) {
+    const int sl = slab0 + round * slab_step;
+    if (sl >= nslab) break;   // block-uniform
+    const int z0 = sl * ZS;
+    const int nz = min(ZS, D - z0);
+    auto scatter = [&](const PointRec& rec, const int4*) {
+      const Cell c = cell_from_record(rec);
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int pz = c.iz + k - z0;
+        if (pz < 0 || pz >= nz) continue;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          if (c.iy + j >= kXG) continue;
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            if (c.ix + e >= kXG) continue;
+            const float wt = c.wz[k] * c.wy[j] * c.wx[e];
+#ifdef DPC_ABLATE
+            if (!DPC_ABL(4) || wt == 123.456f)
+#endif
+            atomicAdd(&acc[(pz * PR + RB + c.iy + j) * kXG + c.ix + e], to_fixed(wt));  // ds_add_u64
+          }
+        }
+      }
+    };
+    if (flat) {
+#pragma unroll
+      for (int r = 0; r < PRE; ++r)
+        if (pre[r].code >= 0) scatter(pre[r], nullptr);
+      for_each_record_flat(cells, b, tab, scatter, npre);
+    } else {
+      for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, scatter);
+    }
+    __syncthreads();
+    if (round == 0) DPC_STAMP(2);
+
+    const bool active = zz < nz;   // wave-uniform: a last slab of fewer planes leaves waves without one
+    const unsigned long long* col = acc + ((size_t)zz * PR + y0) * kXG + lane;  // window row i = grid row y0 + i - RB
+    unsigned long long a[WIN];
+#pragma unroll
+    for (int i = 0; i < WIN; ++i) a[i] = col[i * kXG];
+    // once every thread holds its window the accumulators are free again: open the next slab under the passes below
+    const int sl_next = sl + slab_step;
+    const bool more = round + 1 < nround && sl_next < nslab;
+    RecordRange rr_next{0, 0};
+    if (more) {
+      __syncthreads();
+      rr_next = open_slab(sl_next);
+    }
+    if (active) {
+      // clamp mask: bit x of word y <=> raw <= 1 (raw >= 0 always); 64 lanes = the 64 bits of the row's word.  Lane j keeps
+      // row j's word: the 16 words of this wave leave in one 128-byte store.
+      unsigned long long* mask_out = reinterpret_cast<unsigned long long*>(mask) + ((size_t)b * D + z0 + zz) * kXG + y0;
+      unsigned long long mword = 0ull;
+#pragma unroll
+      for (int j = 0; j < kXSeg; ++j) {
+        const unsigned long long bits = __ballot(a[RB + j] <= kFixOne);
+        mword = lane == j ? bits : mword;
+      }
+      if (lane < kXSeg) mask_out[lane] = mword;
+      float v[WIN];
+#pragma unroll
+      for (int i = 0; i < WIN; ++i) v[i] = fminf(from_fixed(a[i]), 1.0f);
+      if (round == 0) DPC_STAMP(3);
+      // four rows at a time: H pass in registers, W pass across the lanes, then the quad transpose so that every lane
+      // stores 16 contiguous bytes (lane 4q+e: row j+e, x = 4q .. 4q+3)
+      float* Tout = Tbuf + (((size_t)b * D + z0 + zz) * kXG + y0 + (lane & 3)) * kXG + (lane & ~3);
+#pragma unroll
+      for (int j = 0; j < kXSeg; j += 4) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float h = 0.f;
+#ifdef DPC_ABLATE
+          if (DPC_ABL(6)) { o[e] = v[j + e + RB]; continue; }
+#endif
+#pragma unroll
+          for (int tp = 0; tp < 2 * RB + 1; ++tp) h = fmaf(taps.w[tp], v[j + e + tp], h);
+          o[e] = wpass_lanes<RB>(h, taps);
+        }
+        quad_transpose(o, lane);
+#ifdef DPC_ABLATE
+        if (!DPC_ABL(5) || o[0] == 123.456f)
+#endif
+        *reinterpret_cast<f32x4*>(Tout + (size_t)j * kXG) = f32x4{o[0], o[1], o[2], o[3]};
+      }
+    }
+    if (!more) break;
+    request_records(rr_next);
+    zero_rest();
   }
   DPC_STAMP(5);
 }
@@ -217,8 +259,18 @@ int launch_splat_xl_zr(const DpcParams* p, Cells cells, const float* kxy, const 
   static LdsLimit limit;
   int rc = set_lds(kern, lds, limit);
   if (rc != DPC_OK) return rc;
-  DPC_LAUNCH("k_splat_xl", kern, dim3(((p->D + ZS - 1) / ZS) * p->B), dim3(ZS * kXWavesPerPlane * 64), lds, st, *p, cells,
-             make_taps<RB>(kxy, pxy, false), Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
+  // slabs per workgroup (see the kernel): as many as still leave one workgroup per CU
+  const int nslab = (p->D + ZS - 1) / ZS;
+  int nround = 1;
+#ifndef DPC_XL_ONE_SLAB
+#ifndef DPC_XL_WGS_PER_CU
+#define DPC_XL_WGS_PER_CU 1
+#endif
+  for (int c = 2; c <= 16; c *= 2)
+    if (nslab % c == 0 && (size_t)(nslab / c) * p->B >= (size_t)kNumCUs * DPC_XL_WGS_PER_CU) nround = c;
+#endif
+  DPC_LAUNCH("k_splat_xl", kern, dim3((nslab / nround) * p->B), dim3(ZS * kXWavesPerPlane * 64), lds, st, *p, cells,
+             make_taps<RB>(kxy, pxy, false), nround, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
   return launch_ok();
 }
 
