@@ -333,6 +333,8 @@ def main():
                          "(dpc.render.project_loss_step); graph: the autograd path captured into a HIP graph and replayed")
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams inside the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sigma-rel", type=float, default=None,
+                    help="kernel experiments: another smoothing width than the config's (the line then says so in config.workload)")
     ap.add_argument("--split", type=int, default=1,
                     help="the batch of a step as this many independent sub-batches, each its own HIP graph on its own stream, "
                          "joined at the end of every step (steps stay sequential)")
@@ -366,6 +368,8 @@ def main():
     global B, N_PTS, G, SIGMA_REL, K_CAND
     if args.config != "c3" and not args.full_step:
         B, N_PTS, G, SIGMA_REL, K_CAND = CONFIGS[args.config]
+        if args.sigma_rel is not None:
+            SIGMA_REL = args.sigma_rel
     if args.full_step and args.config != "c4":
         raise SystemExit("--full-step is the full-training-step form of --config c4 (c3 is a full step already)")
 

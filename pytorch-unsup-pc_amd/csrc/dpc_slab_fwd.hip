@@ -188,8 +188,30 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
     // accumulator zero-fill: offsets | zero A | table | barrier | records -> registers | zero B | barrier | atomics.
     constexpr int PRE = 2;                 // records prefetched per thread (covers 2*NT points per slab)
     constexpr int ZH = (ACC / 2) / 2;      // float4 words in the first zero-fill half
+    // The workgroup stays for `nround` slabs of its cloud (bk.x, bk.x + nx, ...; the launcher keeps one workgroup per CU):
+    // a workgroup that ends is only replaced once its stores have drained, one that goes on prepares the next slab under
+    // them (k_splat_xl has the measurement).  The next slab's record offsets are requested BEFORE this slab's stores: a
+    // wave's vector memory operations complete in order.
+    const int nround = zs_rt, nslab = (D + ZS - 1) / ZS, slab0 = bk.x, slab_step = bk.nx;
+    const TapsT<RB>& taps_outer = taps;
     RecordRange rr{0, 0};
-    if (flat) rr = load_record_range(cells, b, max(z0 - 1, 0), z0 + nz);
+    if (flat) rr = load_record_range(cells, b, max(slab0 * ZS - 1, 0), slab0 * ZS + min(ZS, D - slab0 * ZS));
+   for (int round = 0; round < nround; ++round) {
+    const int sl = slab0 + round * slab_step;
+    if (sl >= nslab) break;                // block-uniform
+    const int z0 = sl * ZS, nz = min(ZS, D - z0);
+    // the thread id is made opaque every round: otherwise everything a round derives from it (rows, segments, addresses of
+    // five phases) is hoisted in front of the loop and lives through all of it (85 -> 123 registers, spills at radius 10)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    int b = bk.y;                      // likewise the cloud: every global address of a round hangs on it
+    asm volatile("" : "+s"(b));
+    TapsT<RB> taps = taps_outer;       // ... and the taps: their {w, w} pairs for the packed FMAs were built once in front
+#pragma unroll                         // of the loop and parked in VGPR lanes, two v_readlane per use
+    for (int i = 0; i < 2 * RB + 1; ++i) asm volatile("" : "+s"(taps.w[i]));
+    const int sl_next = sl + slab_step;
+    const bool more = round + 1 < nround && sl_next < nslab;
+    if (round > 0) __syncthreads();        // the last slab's fp32 rows have been read
     for (int i = tid; i < ZH; i += Geo::NT) s4[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (flat) finish_record_table(rr, tab);
     __syncthreads();
@@ -300,12 +322,18 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
       }
       __syncthreads();
       DPC_STAMP(4);
+      if (more && flat) {
+        const int zn = sl_next * ZS;
+        rr = load_record_range(cells, b, max(zn - 1, 0), zn + min(ZS, D - zn));
+      }
       float* Tout = Tbuf + ((size_t)b * D + z0) * HW;
       hpass_fast<Geo, GS, RB, ZS, false>(slab, taps, [&](int z, int y, int x, f32x2 v2) {
         if (z < nz) *reinterpret_cast<f32x2*>(Tout + ((size_t)z * GS + y) * GS + x) = v2;
-      });
+      }, tid);
       DPC_STAMP(5);
     }
+    if (!more) break;
+   }
   } else {
     const int WP = odd_stride(W);
     for (int i = tid; i < nz * H * WP; i += nthr) slab[i] = 0.f;
@@ -371,8 +399,17 @@ int launch_splat_fast(const DpcParams* p, Cells cells, const float* kxy, const T
   static LdsLimit limit;
   int rc = set_lds(kern, lds, limit);
   if (rc != DPC_OK) return rc;
-  DPC_LAUNCH("k_splat_hw", kern, dim3(((p->D + ZS - 1) / ZS) * p->B), dim3(Geo::NT), lds, st, *p, cells,
-             make_taps<RB>(kxy, pxy, false), ZS, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
+  // slabs per workgroup (see the kernel): as many as still leave one workgroup per CU; the branches without passes end the
+  // kernel after their one slab
+  const int nslab = (p->D + ZS - 1) / ZS;
+  int nround = 1;
+#ifndef DPC_HW_ONE_SLAB
+  if (Tbuf != nullptr && RB > 0)
+    for (int c = 2; c <= 16; c *= 2)
+      if (nslab % c == 0 && (size_t)(nslab / c) * p->B >= (size_t)kNumCUs) nround = c;
+#endif
+  DPC_LAUNCH("k_splat_hw", kern, dim3((nslab / nround) * p->B), dim3(Geo::NT), lds, st, *p, cells,
+             make_taps<RB>(kxy, pxy, false), nround, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
   return launch_ok();
 }
 

@@ -72,3 +72,15 @@ if (st[:, 4] > 0).any():
 else:  # x-in-lanes kernel: no fp32 slab, no barrier between the passes
     report("k_splat_hw (xl)", [0, 1, 2, 3, 5], ["zero+table", "scatter", "window+mask+convert", "H+W passes+store"])
 report("k_gather_hw", [8, 9, 11, 12, 13], ["pads+H-pass(global)", "gather", "block_sum", "epilogue"])
+
+# backward slab kernel by slab index (clouds % 8 == 0: block L -> slab (L >> 3) % slabs per cloud, dpc_kernels.h block_coords):
+# is the gather phase proportional to the slab's points, or does its first pass cost a fixed price?
+rows = np.nonzero((st[:, 8] > 0) & (st[:, 13] > 0))[0]
+if len(rows) and B % 8 == 0:
+    nx = len(rows) // B
+    print("k_gather_hw by slab (mean over clouds): slab  H-pass  gather  block_sum  epilogue  total")
+    for x in range(nx):
+        sel = rows[(rows >> 3) % nx == x]
+        a = st[sel][:, [8, 9, 11, 12, 13]]
+        d = np.diff(a, axis=1).mean(0)
+        print("    %2d   %6.2f  %6.2f  %6.2f  %6.2f  %6.2f" % (x, d[0], d[1], d[2], d[3], (a[:, -1] - a[:, 0]).mean()))
