@@ -397,6 +397,31 @@ def test_x_in_lanes_kernel_every_radius_bucket(R, O, B, sigma, Gz, with_tf):
             close(gf.grad, cf.grad, TOL, tag + "df")
 
 
+@pytest.mark.parametrize("G,Gz,sigma,B", [(64, 70, 0.64, 32), (64, -1, 3.0, 32), (32, -1, 0.8, 64), (64, 24, 1.0, 88)])
+def test_forward_slab_workgroups_that_stay_for_several_slabs(R, O, G, Gz, sigma, B):
+    """Batches large enough that a forward slab workgroup walks several slabs of its cloud (k_splat_xl and k_splat_hw keep
+    one workgroup per CU): a depth whose last slab has fewer planes than the others (70 = 17 x 4 + 2: waves without a plane
+    still have to reach the barriers), the radius-10 kernel at 64^3, the 32^3 kernel, and a slab count that only halves
+    once (24 planes = 6 slabs, 88 clouds).  Fused one-candidate loss against the oracle."""
+    N = 500
+    cfg = O.Cfg(vox_size=G, vox_size_z=Gz, pc_gauss_kernel_size=21)
+    pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 9700 + B + G)
+    leaf = lambda x: x.clone().requires_grad_(True)
+    cp, cq, cs = leaf(pc), leaf(q), leaf(s)
+    ref = O.pointcloud_project_fast(cfg, cp, cq, None, None, O.smoothing_kernel(cfg, sigma), scaling_factor=cs)
+    rloss = ((ref["proj"] - gt) ** 2).sum() / B
+    rloss.backward()
+    gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+    loss, out, _ = R.pointcloud_project_loss(cfg, gp, gq, None, None, R.smoothing_kernel(cfg, sigma), scaling_factor=gs, gt=dev(gt))
+    loss.backward()
+    tag = "staying G %d Gz %d sigma %g B %d: " % (G, Gz, sigma, B)
+    close(loss, rloss, TOL, tag + "loss")
+    close(out["proj"], ref["proj"], TOL, tag + "proj")
+    close(gp.grad, cp.grad, TOL, tag + "dpc")
+    close(gq.grad, cq.grad, TOL, tag + "dq")
+    close(gs.grad, cs.grad, TOL, tag + "ds")
+
+
 def test_long_kernel_falls_back_to_staged(R, O):
     """Effective radius > 15 voxels exceeds the fused kernels' register window; same answer via stage kernels."""
     cfg = O.Cfg(vox_size=32, pc_gauss_kernel_size=41)
