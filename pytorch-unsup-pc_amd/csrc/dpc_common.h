@@ -422,18 +422,11 @@ __device__ inline double block_sum13_fixed(const float (&vals)[13], float* scrat
     for (int i = 0; i < 13; ++i) scratch[wave * 13 + i] = ws[i];
   }
   __syncthreads();
+  // (all sixteen wave totals requested at once and then added in wave order, instead of this loop of dependent LDS round
+  // trips, measured 0.3-0.4 us SLOWER per step: profiles/r03_ab_runs.txt)
   double tot = 0.0;
-  if (tid < 13) {
-    if (nw <= 16) {   // all wave totals requested at once (the plain loop below is one LDS round trip per wave)
-      float part[16];
-#pragma unroll
-      for (int k = 0; k < 16; ++k) part[k] = k < nw ? scratch[k * 13 + tid] : 0.f;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) tot += (double)part[k];   // wave order; absent waves add an exact zero
-    } else {
-      for (int k = 0; k < nw; ++k) tot += (double)scratch[k * 13 + tid];
-    }
-  }
+  if (tid < 13)
+    for (int k = 0; k < nw; ++k) tot += (double)scratch[k * 13 + tid];
   return tot;
 }
 

@@ -477,53 +477,9 @@ __device__ inline void hpass_fast(const float* slab, const TapsT<RB>& taps, Stor
 template <class Geo, int GS, int RB, int NPL, class Store>
 __device__ inline void hpass_global(const float* __restrict__ src, int planes_present, const TapsT<RB>& taps, Store store) {
   constexpr int ITEMS = NPL * Geo::XP * Geo::NSEGH, IPT = (ITEMS + Geo::NT - 1) / Geo::NT;
-#ifndef DPC_HPASS_TAIL_ITEMS
-  if constexpr (ITEMS > Geo::NT && (NPL - 1) * Geo::XP * Geo::NSEGH == Geo::NT && GS % (Geo::NT / Geo::XP) == 0) {
-    // One plane more than the threads have items for (64^2: 8 + 1 planes, 1152 items for 1024 threads).  As a second item
-    // for the first 128 threads it put a second round trip to memory in front of the barrier every wave waits at; here
-    // every thread takes a sliver of the last plane (LM rows) with its loads in flight TOGETHER with its main item's.
-    constexpr int LM = GS / (Geo::NT / Geo::XP), MWIN = LM + 2 * RB;
-    const int xp = threadIdx.x % Geo::XP, rest = threadIdx.x / Geo::XP;
-    const int z = rest % (NPL - 1), seg = rest / (NPL - 1);
-    const float* col = src + (size_t)z * GS * GS + 2 * xp;
-    const int y0 = seg * Geo::LH - RB;
-    const bool have = z < planes_present;
-    f32x2 v[Geo::HWIN];
-#pragma unroll
-    for (int i = 0; i < Geo::HWIN; ++i) {
-      const int y = y0 + i;
-      const bool in = have && !((i < RB && y < 0) || (i >= Geo::LH + RB && y >= GS));
-      v[i] = in ? *reinterpret_cast<const f32x2*>(col + (size_t)y * GS) : f32x2{0.f, 0.f};
-    }
-    const float* colm = src + (size_t)(NPL - 1) * GS * GS + 2 * xp;
-    const int m0 = rest * LM - RB;
-    const bool have_m = NPL - 1 < planes_present;
-    f32x2 u[MWIN];
-#pragma unroll
-    for (int i = 0; i < MWIN; ++i) {
-      const int y = m0 + i;
-      const bool in = have_m && y >= 0 && y < GS;
-      u[i] = in ? *reinterpret_cast<const f32x2*>(colm + (size_t)y * GS) : f32x2{0.f, 0.f};
-    }
-#pragma unroll
-    for (int j = 0; j < Geo::LH; ++j) {
-      f32x2 acc = f32x2{0.f, 0.f};
-#pragma unroll
-      for (int tp = 0; tp < 2 * RB + 1; ++tp)
-        acc = __builtin_elementwise_fma(f32x2{taps.w[tp], taps.w[tp]}, v[j + tp], acc);
-      store(z, seg * Geo::LH + j, 2 * xp, acc);
-    }
-#pragma unroll
-    for (int j = 0; j < LM; ++j) {
-      f32x2 acc = f32x2{0.f, 0.f};
-#pragma unroll
-      for (int tp = 0; tp < 2 * RB + 1; ++tp)
-        acc = __builtin_elementwise_fma(f32x2{taps.w[tp], taps.w[tp]}, u[j + tp], acc);
-      store(NPL - 1, rest * LM + j, 2 * xp, acc);
-    }
-    return;
-  }
-#endif
+  // (64^2: 8 + 1 planes are 1152 items for 1024 threads, i.e. a second item for the first 128 threads.  Giving every thread a
+  // two-row sliver of the ninth plane instead, its loads in flight together with the main item's, changed nothing: the pass
+  // is bound by the bandwidth of the dT read, 6.2-6.5 us in every slab -- profiles/r03_overlap_experiments.txt item 6.)
 #pragma unroll
   for (int it = 0; it < IPT; ++it) {
     const int item = threadIdx.x + it * Geo::NT;
