@@ -397,12 +397,13 @@ def test_x_in_lanes_kernel_every_radius_bucket(R, O, B, sigma, Gz, with_tf):
             close(gf.grad, cf.grad, TOL, tag + "df")
 
 
-@pytest.mark.parametrize("G,Gz,sigma,B", [(64, 70, 0.64, 32), (64, -1, 3.0, 32), (32, -1, 0.8, 64), (64, 24, 1.0, 88)])
+@pytest.mark.parametrize("G,Gz,sigma,B", [(64, 70, 0.64, 32), (64, -1, 3.0, 32), (32, -1, 0.8, 64), (64, 24, 1.0, 88), (64, -1, 0.64, 33)])
 def test_forward_slab_workgroups_that_stay_for_several_slabs(R, O, G, Gz, sigma, B):
     """Batches large enough that a forward slab workgroup walks several slabs of its cloud (k_splat_xl and k_splat_hw keep
     one workgroup per CU): a depth whose last slab has fewer planes than the others (70 = 17 x 4 + 2: waves without a plane
     still have to reach the barriers), the radius-10 kernel at 64^3, the 32^3 kernel, and a slab count that only halves
-    once (24 planes = 6 slabs, 88 clouds).  Fused one-candidate loss against the oracle."""
+    once (24 planes = 6 slabs, 88 clouds), and a batch off the XCD-aware workgroup map (33 clouds).  Fused one-candidate loss
+    against the oracle."""
     N = 500
     cfg = O.Cfg(vox_size=G, vox_size_z=Gz, pc_gauss_kernel_size=21)
     pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 9700 + B + G)
