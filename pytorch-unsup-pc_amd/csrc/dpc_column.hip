@@ -3,6 +3,7 @@
 // min-of-K selection (k_loss_finalize).  Design notes: DESIGN.md section 4.
 #include "dpc_kernels.h"
 
+
 DPC_DEBUG_SETTERS(col)
 
 namespace dpck {
@@ -276,7 +277,7 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
           acc[r] = a;
         }
         if (!DPC_ABL(18) || acc[0] == 123.456f) {
-          if constexpr (RPL == 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, (float)acc[0]), dst, ray * 4, zo * HW * 4, 0);
+          if constexpr (RPL == 1) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, (float)acc[0]), dst, ray * 4, zo * HW * 4, kAuxThrough);
           else *reinterpret_cast<vec*>(out + (size_t)zo * HW) = acc;
         }
       }
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
           if (zz >= 0 && zz < DD) acc = fmaf(taps_adj.w[k], d[zz], acc);
         }
         if (extra != nullptr) acc += extra[(size_t)zo * HW];
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, acc), dst, ray * 4, zo * HW * 4, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned int, acc), dst, ray * 4, zo * HW * 4, kAuxThrough);
       }
       // keep the unrolled per-voxel chains from being interleaved across voxels (it would spill the columns)
       if ((z & 3) == 3) __builtin_amdgcn_sched_barrier(0);

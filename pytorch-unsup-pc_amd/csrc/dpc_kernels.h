@@ -299,6 +299,22 @@ __device__ inline void hpass(float* slab, int nz, int H, int W, int WP, const Ta
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Write-through stores (the sc1 bit) for the big streams a kernel writes and does not read again: T, dT.
+// An ordinary store is acknowledged by the L2 and its line stays dirty there; the whole written volume -- a c2 grid is
+// 33.5 MB, the eight L2s hold 32 MB -- is then flushed when the kernel ends, after the last wave: 3-7 us in which the CUs
+// do nothing.  Written through, the stream goes to memory WHILE the kernel still computes.  Measured on the c2 step
+// (same box, alternating builds, profiles/r03_ab_runs.txt): T -1.6..-2.2 us, dT -1.6..-2.2 us, together 55.9 -> 51.7 us.
+// The non-temporal bit instead of sc1 gains the same in the writing kernel and loses it again in the reading one (the
+// lines do not stay in the memory-side cache).  Relaxed agent-scope atomic stores are how the compiler is asked for
+// "global_store ... sc1"; they are plain stores to memory otherwise (no ordering is implied or needed: the consumer is
+// the next kernel).
+__device__ inline void store_through(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void store_through(f32x2* p, f32x2 v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), __builtin_bit_cast(unsigned long long, v), __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+constexpr int kAuxThrough = 16;   // the same bit for the raw-buffer store builtins (cache policy operand: sc1)
+
 template <int GS, int RB, int NT_, int LW_, int LH_>
 struct SlabGeo {
   static constexpr int PAD = RB <= 4 ? 4 : ((RB + 3) / 4) * 4;

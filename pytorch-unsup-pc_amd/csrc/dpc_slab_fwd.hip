@@ -134,6 +134,7 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
   uint8_t* out = cells_out + ((size_t)b * bk.nx + blk) * chunk;
   const int npts = min(kLocThreads, P.N - blk * kLocThreads);
   if (tid < npts) {
+    // (ordinary stores: written through, these 32-byte-per-thread record stores cost k_locate 0.4 us at c2 and 4.7 us at c5)
     reinterpret_cast<int4*>(out)[tid] = stage[tid];
     reinterpret_cast<int4*>(out + (size_t)kLocThreads * sizeof(PointRec))[tid] = stage[kLocThreads + tid];
   }
@@ -328,7 +329,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
       }
       float* Tout = Tbuf + ((size_t)b * D + z0) * HW;
       hpass_fast<Geo, GS, RB, ZS, false>(slab, taps, [&](int z, int y, int x, f32x2 v2) {
-        if (z < nz) *reinterpret_cast<f32x2*>(Tout + ((size_t)z * GS + y) * GS + x) = v2;
+        if (z < nz) store_through(reinterpret_cast<f32x2*>(Tout + ((size_t)z * GS + y) * GS + x), v2);   // dpc_kernels.h
       }, tid);
       DPC_STAMP(5);
     }

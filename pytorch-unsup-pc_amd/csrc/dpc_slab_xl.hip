@@ -31,25 +31,6 @@ __device__ inline float dpp_zero_fill(float v) {
 __device__ inline float from_lane_below(float v) { return dpp_zero_fill<0x138>(v); }  // wave_shr:1, lane x reads lane x-1
 __device__ inline float from_lane_above(float v) { return dpp_zero_fill<0x130>(v); }  // wave_shl:1, lane x reads lane x+1
 
-// 4 x 4 transpose inside every quad of lanes (two rounds of pairwise exchanges over DPP quad permutes): on entry lane e of
-// a quad holds r[j] = element (row j, column e); on exit it holds r[j] = element (row e, column j).  Turns "one x, four
-// rows" into "four consecutive x of one row": 16-byte global accesses for kernels that keep x in the lanes.
-__device__ inline void quad_transpose(float (&r)[4], int lane) {
-  const bool b0 = lane & 1, b1 = lane & 2;
-#pragma unroll
-  for (int j = 0; j < 4; j += 2) {  // lanes e, e^1 exchange across registers j, j+1
-    const float got = dpp_zero_fill<0xb1>(b0 ? r[j] : r[j + 1]);   // quad_perm:[1,0,3,2]
-    r[j + 1] = b0 ? r[j + 1] : got;
-    r[j] = b0 ? got : r[j];
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {     // lanes e, e^2 exchange across registers j, j+2
-    const float got = dpp_zero_fill<0x4e>(b1 ? r[j] : r[j + 2]);   // quad_perm:[2,3,0,1]
-    r[j + 2] = b1 ? r[j + 2] : got;
-    r[j] = b1 ? got : r[j];
-  }
-}
-
 // out(x) = sum_t w[t] in(x + t - RB) over the 64 lanes of the wave, zero outside the row
 template <int RB>
 __device__ inline float wpass_lanes(float v, const TapsT<RB>& taps) {
@@ -220,9 +201,8 @@ __global__ __launch_bounds__(ZS * kXWavesPerPlane * 64) void k_splat_xl(DpcParam
 #pragma unroll
       for (int i = 0; i < WIN; ++i) v[i] = fminf(from_fixed(a[i]), 1.0f);
       if (round == 0) DPC_STAMP(3);
-      // four rows at a time: H pass in registers, W pass across the lanes, then the quad transpose so that every lane
-      // stores 16 contiguous bytes (lane 4q+e: row j+e, x = 4q .. 4q+3)
-      float* Tout = Tbuf + (((size_t)b * D + z0 + zz) * kXG + y0 + (lane & 3)) * kXG + (lane & ~3);
+      // four rows at a time: H pass in registers, W pass across the lanes, four row stores
+      float* Tout = Tbuf + (((size_t)b * D + z0 + zz) * kXG + y0) * kXG + lane;
 #pragma unroll
       for (int j = 0; j < kXSeg; j += 4) {
         float o[4];
@@ -236,11 +216,14 @@ __global__ __launch_bounds__(ZS * kXWavesPerPlane * 64) void k_splat_xl(DpcParam
           for (int tp = 0; tp < 2 * RB + 1; ++tp) h = fmaf(taps.w[tp], v[j + e + tp], h);
           o[e] = wpass_lanes<RB>(h, taps);
         }
-        quad_transpose(o, lane);
+        // one grid row per store instruction (lane = x: 256 contiguous bytes), written through (dpc_kernels.h)
 #ifdef DPC_ABLATE
         if (!DPC_ABL(5) || o[0] == 123.456f)
 #endif
-        *reinterpret_cast<f32x4*>(Tout + (size_t)j * kXG) = f32x4{o[0], o[1], o[2], o[3]};
+        {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) store_through(Tout + (size_t)(j + e) * kXG, o[e]);
+        }
       }
     }
     if (!more) break;

@@ -1,0 +1,15 @@
+#!/bin/bash
+# cache policy of the two big store streams (T from the forward slab kernel, dT from the column kernel)
+set -o pipefail
+cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/r03i; rm -rf $OUT; mkdir -p $OUT
+for rep in 1 2; do
+  for v in product zsc1 ssc1zsc1; do
+    if [ $v = product ]; then unset DPC_RENDER_LIB; else export DPC_RENDER_LIB=$PWD/scratch/$v/libdpc_render.so; fi
+    echo "== $v rep $rep" >> $OUT/ab.txt
+    timeout -k 10 200 python tools/bench_step.py 400 2>&1 | grep -v "amdgpu.ids\|status word" >> $OUT/ab.txt
+  done
+done
+cat $OUT/ab.txt
+export DPC_RENDER_LIB=$PWD/scratch/ssc1zsc1/libdpc_render.so
+timeout -k 10 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
