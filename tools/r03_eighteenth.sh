@@ -1,9 +1,9 @@
 #!/bin/bash
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
-OUT=gpurun_out/r03l; rm -rf $OUT; mkdir -p $OUT
+OUT=gpurun_out/r03m; rm -rf $OUT; mkdir -p $OUT
 for rep in 1 2; do
-  for v in product one2 locnt; do
+  for v in product zst100 zst250 zst400; do
     if [ $v = product ]; then unset DPC_RENDER_LIB; else export DPC_RENDER_LIB=$PWD/scratch/$v/libdpc_render.so; fi
     echo "== $v rep $rep" >> $OUT/ab.txt
     timeout -k 10 200 python tools/bench_step.py 400 2>&1 | grep -v "amdgpu.ids\|status word" >> $OUT/ab.txt
