@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
         if (mask_out != nullptr && present && (tid & 63) == 0) mask_out[i >> 6] = bits;
         const float v = to_float(a);
         if (raw != nullptr && present) raw[((size_t)b * D + z0) * HW + i] = v;
-        if (Tbuf != nullptr && present) Tbuf[((size_t)b * D + z0) * HW + i] = w2 * fminf(v, 1.0f);
+        if (Tbuf != nullptr && present) store_through(Tbuf + ((size_t)b * D + z0) * HW + i, w2 * fminf(v, 1.0f));
       }
       return;
     } else {
@@ -381,12 +381,12 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
       const float w2 = taps.w[0] * taps.w[0];
       for (int i = tid; i < nz * H * W; i += nthr) {
         const int x = i % W, zy = i / W;
-        Tout[i] = w2 * fminf(slab[zy * WP + x], 1.0f);
+        store_through(Tout + i, w2 * fminf(slab[zy * WP + x], 1.0f));
       }
       return;
     }
     wpass_inplace<RB, true>(slab, nz, H, W, WP, taps, [](int, int, float val) { return val; });
-    hpass<RB>(slab, nz, H, W, WP, taps, [&](int z, int y, int x, float val) { Tout[(z * H + y) * W + x] = val; });
+    hpass<RB>(slab, nz, H, W, WP, taps, [&](int z, int y, int x, float val) { store_through(Tout + (z * H + y) * W + x, val); });
   }
 }
 

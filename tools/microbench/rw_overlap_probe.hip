@@ -13,6 +13,25 @@
 __global__ __launch_bounds__(256) void k_fill(float4* dst, size_t n4, float v) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) dst[i] = float4{v, v, v, v};
 }
+// the same stream written through (sc1): one dword per lane per store, like the forward slab kernel's row stores
+__global__ __launch_bounds__(256) void k_fill_through(float* dst, size_t n, float v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(256) void k_fill_dword(float* dst, size_t n, float v) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) dst[i] = v;
+}
+// a kernel that computes for `ticks` (100 MHz) and THEN stores its 33.5 MB: how much of the store stream hides under the
+// next workgroups' compute when there are two rounds of workgroups, written back or written through?
+__global__ __launch_bounds__(1024) void k_compute_then_store(float* dst, size_t per_block, int ticks, int through) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(2);
+  float* d = dst + (size_t)blockIdx.x * per_block;
+  for (size_t i = threadIdx.x; i < per_block; i += blockDim.x) {
+    if (through) __hip_atomic_store(d + i, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else d[i] = 1.0f;
+  }
+}
 __global__ __launch_bounds__(256) void k_read(const float4* src, size_t n4, float* sink) {
   float acc = 0.f;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
@@ -63,6 +82,7 @@ int main() {
   CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&sink, 64));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_compute_then_store), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
   auto timed = [&](const char* name, auto launch) {
     std::vector<float> us;
     for (int i = 0; i < 30; ++i) {
@@ -80,6 +100,10 @@ int main() {
   for (int rep = 0; rep < 2; ++rep) {
     timed("empty event pair", [&] {});
     timed("write-only 33.5 MB", [&] { hipLaunchKernelGGL(k_fill, dim3(2048), dim3(256), 0, 0, b, n4, 2.0f); });
+    timed("write-only 33.5 MB, dword stores", [&] { hipLaunchKernelGGL(k_fill_dword, dim3(2048), dim3(256), 0, 0, (float*)b, n4 * 4, 2.0f); });
+    timed("write-only 33.5 MB, dword stores written through (sc1)", [&] { hipLaunchKernelGGL(k_fill_through, dim3(2048), dim3(256), 0, 0, (float*)b, n4 * 4, 2.0f); });
+    timed("512 workgroups: 4 us of compute, then 64 KB of stores each", [&] { hipLaunchKernelGGL(k_compute_then_store, dim3(512), dim3(1024), 140 * 1024, 0, (float*)b, n4 * 4 / 512, 400, 0); });
+    timed("the same, stores written through (sc1)", [&] { hipLaunchKernelGGL(k_compute_then_store, dim3(512), dim3(1024), 140 * 1024, 0, (float*)b, n4 * 4 / 512, 400, 1); });
     timed("read-only 33.5 MB (just written)", [&] { hipLaunchKernelGGL(k_read, dim3(2048), dim3(256), 0, 0, a, n4, sink); });
     timed("copy 33.5 -> 33.5 MB, load/store interleaved", [&] { hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, a, b, n4); });
     timed("copy, every thread loads 16 then stores 16", [&] { hipLaunchKernelGGL(k_phased, dim3((unsigned)((n4 + 4095) / 4096)), dim3(256), 0, 0, a, b, n4); });
