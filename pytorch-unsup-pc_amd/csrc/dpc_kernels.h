@@ -340,7 +340,9 @@ constexpr int bwd_threads(int gs, int npl) {
   return items >= 1024 ? 1024 : (items <= 256 ? 256 : ((items + 63) / 64) * 64);
 }
 template <int GS, int RB, int NPL>
-using BwdGeo = SlabGeo<GS, RB, bwd_threads(GS, NPL), 32, 16>;
+// 128-wide planes: 8-row H-pass segments -- a one-plane step of the rolling backward then has an item for every one of
+// its 1024 threads (16-row segments left half of them idle under a latency-bound load: k_gather_hw<128,1,8> 41.9 -> 38.7 us)
+using BwdGeo = SlabGeo<GS, RB, bwd_threads(GS, NPL), 32, (GS == 128 ? 8 : 16)>;
 
 constexpr float kFixScale = 17592186044416.0f;          // 2^44: splat weights accumulate as 64-bit fixed point
 constexpr float kFixInv = 1.0f / 17592186044416.0f;
