@@ -215,3 +215,46 @@ def test_camera_gradient_hand_off_carries_sc1_in_the_isa():
     first_store = next(i for i, l in enumerate(lines) if "global_store_dwordx2" in l and "sc1" in l)
     ticket = next(i for i, l in enumerate(lines) if i > first_store and "global_atomic_add" in l and "sc0" in l)   # returning add
     assert any("s_waitcnt vmcnt(0)" in l for l in lines[first_store:ticket]), "no vmcnt(0) between the hand-off stores and the ticket"
+
+
+def _device_asm(obj_name):
+    import subprocess
+    import tempfile
+
+    obj = os.path.join(ROOT, "pytorch-unsup-pc_amd", "csrc", obj_name)
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not (os.path.exists(obj) and os.path.exists(objdump)):
+        pytest.skip("needs the built object file and llvm-objdump")
+    with tempfile.TemporaryDirectory() as tmp:
+        subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objcopy", "--dump-section", ".hip_fatbin=" + tmp + "/fb.bin", obj],
+                       check=True, capture_output=True)
+        subprocess.run(["/opt/rocm/lib/llvm/bin/clang-offload-bundler", "--type=o", "--unbundle",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--input=" + tmp + "/fb.bin", "--output=" + tmp + "/dev.o"],
+                       check=True, capture_output=True)
+        return subprocess.run([objdump, "-d", tmp + "/dev.o"], check=True, capture_output=True, text=True).stdout
+
+
+def _kernel_body(asm, mangled_fragment):
+    import re
+
+    m = re.search(r"<_ZN4dpck\S*" + mangled_fragment + r"\S*>:\n(.*?)\n\n", asm, re.S)
+    assert m, mangled_fragment + " not found in the disassembly"
+    return m.group(1).splitlines()
+
+
+def test_grid_sized_store_streams_are_written_through_in_the_isa():
+    """T (forward slab kernels) and dT (column kernels) leave with the sc1 bit -- store_through / kAuxThrough in
+    csrc/dpc_kernels.h: without it the L2s hold a whole grid dirty until the kernel ends (4 us of the c2 step, DESIGN.md
+    section 4).  The bit is a property of the generated code: every grid store of the benchmark configuration's kernels
+    carries it, and the small scattered stores that measured slower written through do not."""
+    xl = _kernel_body(_device_asm("dpc_slab_xl.o"), "k_splat_xlILi4ELi3E")
+    rows = [l for l in xl if "global_store_dword " in l]
+    plain = [l for l in rows if "sc1" not in l]   # the per-cloud words the kernel zeroes for the ray-march kernel
+    assert len(rows) - len(plain) >= 16 and len(plain) <= 4, (len(rows), plain[:5])
+    col = _kernel_body(_device_asm("dpc_column.o"), "k_zcol_fwdbwdILi64ELi3ELi1E")
+    dts = [l for l in col if "buffer_store_dword " in l]
+    assert len(dts) >= 64 and all("sc1" in l for l in dts), (len(dts), [l for l in dts if "sc1" not in l][:3])
+    hw = _kernel_body(_device_asm("dpc_slab_fwd.o"), "k_splat_hwILi128ELi1ELi8E")
+    assert any("global_store_dwordx2" in l and "sc1" in l for l in hw), "k_splat_hw<128,1,8> stores T without sc1"
+    loc = _kernel_body(_device_asm("dpc_slab_fwd.o"), "k_locateILi0E")
+    assert not any("global_store" in l and "sc1" in l for l in loc), "k_locate's record stores are meant to be ordinary"
