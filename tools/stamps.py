@@ -67,7 +67,11 @@ def report(name, slots, labels):
           " end deciles", np.round(np.percentile(end, [0, 10, 25, 50, 75, 90, 100]), 2))
 
 
-if (st[:, 4] > 0).any():
+if (st[:, 14] > 0).any():  # x-in-lanes kernel staying for two slabs
+    report("k_splat_xl (two slabs)", [0, 1, 2, 3, 4, 14, 6, 7, 5],
+           ["slab 0: zero+table", "slab 0: scatter", "slab 0: window+mask+convert", "slab 0: passes+stores issued",
+            "slab 1: table+records+zero", "slab 1: scatter", "slab 1: window+mask+convert", "slab 1: passes+stores issued"])
+elif (st[:, 4] > 0).any():
     report("k_splat_hw", [0, 1, 2, 3, 4, 5], ["zero+table", "scatter", "W-load/convert", "W-compute/write", "H-pass+store"])
 else:  # x-in-lanes kernel: no fp32 slab, no barrier between the passes
     report("k_splat_hw (xl)", [0, 1, 2, 3, 5], ["zero+table", "scatter", "window+mask+convert", "H+W passes+store"])
