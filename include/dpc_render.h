@@ -18,7 +18,10 @@
  *     dpc_project_loss_fwd writes loss = 0;
  *   - re-entrant, no global state; arithmetic type fp32 (the ray-march transmittance product runs in fp64
  *     registers); tensors are dense row-major with the shapes stated per argument;
- *   - optional inputs (t, f, s) and optional outputs are NULL when absent.
+ *   - optional inputs (t, f, s) and optional outputs are NULL when absent;
+ *   - grids, silhouettes and the workspace are read and written with 8- and 16-byte accesses: their base pointers must be
+ *     16-byte aligned (anything hipMalloc returns is); the big grids a launch writes and does not read again (the W/H-
+ *     filtered grid, its gradient) are stored write-through, which needs nothing from the caller.
  *
  * Grid: D x H x W voxels (D = vox_size_z or vox_size, H = W = vox_size), voxel (z,y,x) of cloud b at
  * [((b*D + z)*H + y)*W + x].  Point clouds are [B,N,3] xyz, quaternions [B,4] (w,x,y,z) unnormalised.
