@@ -423,6 +423,35 @@ def test_forward_slab_workgroups_that_stay_for_several_slabs(R, O, G, Gz, sigma,
     close(gs.grad, cs.grad, TOL, tag + "ds")
 
 
+@pytest.mark.parametrize("B,N,G,sigma", [(9, 1200, 64, 0.64), (33, 2000, 64, 0.3), (3, 3000, 128, 1.0)])
+def test_write_through_grids_are_never_read_stale(R, O, B, N, G, sigma):
+    """The W/H-filtered grid and its gradient are written THROUGH the L2s (csrc/dpc_kernels.h, store_through) and read by
+    the next kernel with ordinary loads -- on workgroups of other XCDs too when the batch is off the XCD map.  One step
+    plan (static buffers, so every call reuses the same addresses) alternates between three input sets while other kernels
+    churn through the caches in between: every result must stay bit-identical to the first one of its input set."""
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=21)
+    kern = R.smoothing_kernel(cfg, sigma)
+    d = torch.device("cuda")
+    sets = [[dev(x) for x in O.synth_inputs(B, N, G, 4200 + k)[:4]] for k in range(3)]
+    plan = R.project_loss_step(cfg, kern, B, N, d)
+    first = []
+    for k in range(3):
+        plan.run(*sets[k])
+        torch.cuda.synchronize()
+        first.append([t.clone() for t in (plan.loss, plan.dpc, plan.dq, plan.ds, plan.proj)])
+    junk = torch.empty(48 << 20, device=d)
+    for it in range(30):
+        k = it % 3
+        if it % 4 == 0:
+            junk.normal_()
+        plan.run(*sets[k])
+        if it % 5 == 0:
+            (junk[: 1 << 20] * 2).sum()
+        torch.cuda.synchronize()
+        for name, a, b_ in zip(("loss", "dpc", "dq", "ds", "proj"), (plan.loss, plan.dpc, plan.dq, plan.ds, plan.proj), first[k]):
+            assert torch.equal(a, b_), "call %d (input set %d): %s differs from the first run" % (it, k, name)
+
+
 def test_long_kernel_falls_back_to_staged(R, O):
     """Effective radius > 15 voxels exceeds the fused kernels' register window; same answer via stage kernels."""
     cfg = O.Cfg(vox_size=32, pc_gauss_kernel_size=41)
