@@ -759,6 +759,14 @@ struct Workspace {
 constexpr double kGradFixScale = 1099511627776.0;          // 2^40
 constexpr double kGradFixInv = 1.0 / 1099511627776.0;
 __device__ inline unsigned long long grad_to_fixed(float v) { return (unsigned long long)(long long)__double2ll_rn((double)v * kGradFixScale); }
+// A contribution that is not a finite number below this bound (a diverged network: NaN scale, Inf gradient) has no integer to
+// stand for it -- the conversion would turn it into a healthy-looking value.  It is not added; the point set's POISON word
+// (one per set, behind the fixed-point sums) is set instead and k_fixed_to_dpc writes NaN for that set's gradient, so the
+// divergence reaches the decoder as it does through the reference's float sums (where NaN + x = NaN).
+constexpr float kGradFixMax = 1048576.0f;                   // 2^20 per contribution
+__device__ inline bool grad_fits_fixed(float x, float y, float z) {
+  return fabsf(x) < kGradFixMax && fabsf(y) < kGradFixMax && fabsf(z) < kGradFixMax;   // NaN fails every comparison
+}
 inline size_t ws_round(size_t n) { return (n + 255) / 256 * 256; }
 inline size_t ws_grid_bytes(const DpcParams* p) { return ws_round((size_t)p->B * p->D * p->H * p->W * sizeof(float)); }
 inline size_t ws_parts_bytes(const DpcParams* p) {
@@ -766,9 +774,10 @@ inline size_t ws_parts_bytes(const DpcParams* p) {
 }
 inline size_t ws_camgrad_bytes(const DpcParams* p) { return ws_round((size_t)p->B * p->D * 16 * sizeof(double)); }
 inline bool shares_points(const DpcParams* p) { return p->point_replicas > 1 || p->point_index != nullptr; }
-inline size_t ws_dpcfix_bytes(const DpcParams* p) {
+inline size_t ws_dpcfix_bytes(const DpcParams* p) {   // the sums, then one poison word per point set
   const int reps = p->point_replicas > 1 ? p->point_replicas : 1;
-  return shares_points(p) ? ws_round((size_t)(p->B / reps) * points_per_set(*p) * 3 * sizeof(unsigned long long)) : 0;
+  const size_t sets = (size_t)(p->B / reps);
+  return shares_points(p) ? ws_round(sets * points_per_set(*p) * 3 * sizeof(unsigned long long) + sets * sizeof(unsigned int)) : 0;
 }
 inline size_t ws_total_bytes(const DpcParams* p) {
   return ws_grid_bytes(p) + ws_parts_bytes(p) + ws_camgrad_bytes(p) + ws_round((size_t)p->B * sizeof(unsigned int)) + ws_dpcfix_bytes(p);

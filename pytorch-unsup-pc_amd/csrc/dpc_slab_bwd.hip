@@ -230,8 +230,12 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     if (shared_points && !single_writer) {
       // several clouds add into this point set's gradient: 64-bit fixed-point adds (exact, so the sum does not depend on
       // who arrives first); k_fixed_to_dpc turns the sums into floats behind this launch
-      unsigned long long* acc = dpc_fixed + ((size_t)(b / reps) * Nset + i) * 3;
-      atomicAdd(acc + 0, grad_to_fixed(dpx)); atomicAdd(acc + 1, grad_to_fixed(dpy)); atomicAdd(acc + 2, grad_to_fixed(dpz));
+      if (grad_fits_fixed(dpx, dpy, dpz)) {
+        unsigned long long* acc = dpc_fixed + ((size_t)(b / reps) * Nset + i) * 3;
+        atomicAdd(acc + 0, grad_to_fixed(dpx)); atomicAdd(acc + 1, grad_to_fixed(dpy)); atomicAdd(acc + 2, grad_to_fixed(dpz));
+      } else {   // NaN / Inf / out of range: poison the set (dpc_kernels.h), k_fixed_to_dpc writes NaN
+        atomicOr(reinterpret_cast<unsigned int*>(dpc_fixed + (size_t)(P.B / reps) * Nset * 3) + b / reps, 1u);
+      }
     } else {
       // (ordinary stores: these 12-byte scattered writes cost the kernel 4 us when written through)
       dcloud[3 * i + 0] = dpx; dcloud[3 * i + 1] = dpy; dcloud[3 * i + 2] = dpz;
@@ -297,10 +301,13 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   DPC_STAMP(13);
 }
 
-// d(point sets) += the fixed-point sums the gather left (shared point sets with several writers)
-__global__ __launch_bounds__(256) void k_fixed_to_dpc(const unsigned long long* __restrict__ acc, float* __restrict__ dpc, size_t n) {
+// d(point sets) += the fixed-point sums the gather left (shared point sets with several writers); a set that received a
+// contribution with no fixed-point value (NaN, Inf, out of range: its poison word is set) gets NaN instead
+__global__ __launch_bounds__(256) void k_fixed_to_dpc(const unsigned long long* __restrict__ acc, float* __restrict__ dpc, size_t n,
+                                                       size_t per_set) {
+  const unsigned int* poison = reinterpret_cast<const unsigned int*>(acc + n);
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
-    dpc[i] += (float)((double)(long long)acc[i] * kGradFixInv);
+    dpc[i] = poison[i / per_set] != 0u ? __int_as_float(0x7fc00000) : dpc[i] + (float)((double)(long long)acc[i] * kGradFixInv);
 }
 
 // several clouds write into one point set's gradient (the kernel's own test, see k_gather_hw)
@@ -379,14 +386,15 @@ int launch_gather(int bucket, const DpcParams* p, Cells cells, const float* pc, 
   const size_t nfix = (size_t)(p->B / reps) * points_per_set(*p) * 3;
   if (fixed) {
     if (dpc_fixed == nullptr) return DPC_ERR_NULL;
-    if (!zero_words_async(dpc_fixed, 2 * nfix, st)) return DPC_ERR_LAUNCH;   // a kernel, not a memset node (dpc_common.h)
+    // the sums and the poison words behind them; a kernel, not a memset node (dpc_common.h)
+    if (!zero_words_async(dpc_fixed, 2 * nfix + (size_t)(p->B / reps), st)) return DPC_ERR_LAUNCH;
   }
   int rc = DPC_OK;
 #define DPC_GATHER(RB) rc = launch_gather_rb<RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed)
   DPC_FOR_BUCKET(bucket, DPC_GATHER)
 #undef DPC_GATHER
   if (rc != DPC_OK || !fixed) return rc;
-  DPC_LAUNCH("k_fixed_to_dpc", k_fixed_to_dpc, dim3((unsigned)std::min<size_t>((nfix + 255) / 256, 2048)), dim3(256), 0, st, dpc_fixed, dpc, nfix);
+  DPC_LAUNCH("k_fixed_to_dpc", k_fixed_to_dpc, dim3((unsigned)std::min<size_t>((nfix + 255) / 256, 2048)), dim3(256), 0, st, dpc_fixed, dpc, nfix, (size_t)points_per_set(*p) * 3);
   return launch_ok();
 }
 

@@ -67,7 +67,9 @@ class TrainStep:
         self.optimizer = torch.optim.Adam(self.nets.parameters(), lr=lr, weight_decay=cfg.weight_decay,
                                           capturable=capturable, fused=bool(fused_adam))  # train_to.py:73-74
         self._graph = None
-        self._schedule = None      # dpc.render.DeviceSchedule while a graph is being captured / replayed
+        self._schedule = None      # dpc.render.DeviceSchedule ONLY while a graph is being captured (record() below): an eager
+                                   # loss() / __call__ on this object afterwards computes its values from the step it is asked for
+        self._captured_schedule = None   # the schedule the current graph's kernels read; rewritten in front of every replay
         self.recaptures = 0
         self.global_step = 0
         self.grad_sync, self.sync_samples = None, (1, 1)
@@ -154,11 +156,11 @@ class TrainStep:
         """In front of a replay: write this step's values into device memory -- or, when they no longer fit what the graph
         was captured for (sigma crossed into another tap window, the live points outgrew the rows), capture again."""
         kxy, kz, n_live = self._schedule_values(self.global_step)
-        if not self._schedule.tight(kxy, kz, n_live):
+        if not self._captured_schedule.tight(kxy, kz, n_live):
             recapture()
             self.recaptures += 1
         else:
-            self._schedule.update(kxy, kz, n_live)
+            self._captured_schedule.update(kxy, kz, n_live)
 
     def capture_compute(self, images, masks, warmup=2):
         """The multi-rank variant of capture(): forward, loss and backward as ONE HIP graph whose backward accumulates
@@ -185,13 +187,16 @@ class TrainStep:
         state = {}
 
         def record():
-            self._schedule = self._new_schedule(self.global_step)
+            self._captured_schedule = self._schedule = self._new_schedule(self.global_step)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                for flat in sync.flat:
-                    flat.zero_()
-                total, _ = self.loss(static_images, static_masks)
-                total.backward()              # the hooks are disarmed: gradients simply land in the buckets
+            try:
+                with torch.cuda.graph(graph):
+                    for flat in sync.flat:
+                        flat.zero_()
+                    total, _ = self.loss(static_images, static_masks)
+                    total.backward()              # the hooks are disarmed: gradients simply land in the buckets
+            finally:
+                self._schedule = None             # the captured kernels keep the pointers; eager calls do not see it
             self._graph, state["graph"], state["loss"] = graph, graph, total.detach()
 
         record()
@@ -237,13 +242,16 @@ class TrainStep:
         state = {}
 
         def record():
-            self._schedule = self._new_schedule(self.global_step)
+            self._captured_schedule = self._schedule = self._new_schedule(self.global_step)
             self.optimizer.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                total, _ = self.loss(static_images, static_masks)
-                total.backward()
-                self.optimizer.step()
+            try:
+                with torch.cuda.graph(graph):
+                    total, _ = self.loss(static_images, static_masks)
+                    total.backward()
+                    self.optimizer.step()
+            finally:
+                self._schedule = None             # the captured kernels keep the pointers; eager calls do not see it
             self._graph, state["graph"], state["loss"] = graph, graph, total.detach()
 
         record()

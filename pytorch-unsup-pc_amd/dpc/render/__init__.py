@@ -307,6 +307,20 @@ class ProjectionOutputs(dict):
         return dict.items(self)
 
 
+_OUTSIDE = 2.0   # a coordinate outside the unit cube [-1/2, 1/2]^3: such a point splats nothing (point_cloud_to.py:26-27)
+
+
+def _mask_dead_slots(tr, schedule):
+    """Under a DeviceSchedule with a live-point count, a cloud's row has `capacity` slots of which only the first *n_live hold
+    points (k_locate turns the others into out-of-bounds records).  The stage-level path does the same without reading the
+    count on the host (so it stays capturable): the transformed coordinates of the dead slots are replaced by a constant
+    outside the unit cube -- no splat, no gradient -- which is also what `tr_pc` shows in those slots."""
+    if schedule is None or schedule.n_live is None:
+        return tr
+    dead = (torch.arange(tr.shape[1], device=tr.device, dtype=torch.int32) >= schedule.n_live).view(1, -1, 1)
+    return torch.where(dead, torch.full_like(tr, _OUTSIDE), tr)
+
+
 def _outputs_from_grid(cfg, geom, grid_wh, pc, q, t, f, s, point_index):
     """Lazy entries of the output dict derived from what the fused forward left behind: `tr_pc` is one transform launch;
     `voxels`, `drc_probs`, `proj_depth` start from grid_wh (the grid after clamp and the W, H passes, a differentiable
@@ -318,7 +332,7 @@ def _outputs_from_grid(cfg, geom, grid_wh, pc, q, t, f, s, point_index):
             pts = pts.repeat_interleave(q.shape[0] // pts.shape[0], dim=0)
         if point_index is not None:
             pts = pts.gather(1, point_index.long().unsqueeze(-1).expand(-1, -1, 3))
-        return {"tr_pc": Transform.apply(pts, q, t, f, geom)}
+        return {"tr_pc": _mask_dead_slots(Transform.apply(pts, q, t, f, geom), geom.schedule)}
 
     cache = {}
 
@@ -349,7 +363,7 @@ def _project_staged(cfg, geom, pc, q, t, f, s, smooth, point_index=None):
         pc = pc.repeat_interleave(q.shape[0] // pc.shape[0], dim=0)
     if point_index is not None:    # every cloud's own subset, materialised
         pc = pc.gather(1, point_index.long().unsqueeze(-1).expand(-1, -1, 3))
-    tr = Transform.apply(pc, q, t, f, geom)
+    tr = _mask_dead_slots(Transform.apply(pc, q, t, f, geom), geom.schedule)
     raw = Splat.apply(tr, geom)
     vox = torch.clamp(raw, 0.0, 1.0)
     if smooth and geom.kxy is not None:

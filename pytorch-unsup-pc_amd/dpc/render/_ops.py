@@ -113,6 +113,12 @@ class DeviceSchedule:
         kz = np.ascontiguousarray(kz, dtype=np.float32).reshape(-1)
         if (kxy.size, kz.size) != self.sizes:
             raise ValueError("the schedule was built for kernels of %s taps, got %s" % (self.sizes, (kxy.size, kz.size)))
+        if not self.fits(kxy, kz, n_live):
+            # the kernels that read these values were compiled / captured for the tap windows `buckets` and rows of `capacity`
+            # slots: taps outside the window would be dropped silently, points beyond the rows never read
+            raise ValueError("schedule values do not fit what the schedule was built for: tap windows %s (needed %s), capacity %s "
+                             "(n_live %s) -- build a new DeviceSchedule (and capture again)"
+                             % (self.buckets, (taps_bucket(kxy), taps_bucket(kz)), self.capacity, n_live))
         with torch.cuda.device(self.device):
             rc = N.lib().dpc_schedule_update(kxy.ctypes.data_as(ctypes.c_void_p), kxy.size, kz.ctypes.data_as(ctypes.c_void_p),
                                              kz.size, 0 if n_live is None else int(n_live), N.ptr(self.taps_xy),

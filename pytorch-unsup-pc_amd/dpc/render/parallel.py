@@ -103,9 +103,12 @@ class OverlappedGradAllReduce:
     tensor would pay one collective latency per layer.
     """
 
-    def __init__(self, params, bucket_mb=32, group=None, overlap=True):
+    def __init__(self, params, bucket_mb=32, group=None, overlap=True, single_rank_collectives=False):
+        """single_rank_collectives: issue the all-reduces even in a process group of ONE rank (they are identities there).
+        A world of one normally skips them; with this flag the very code path of N ranks -- librccl loaded, the collectives
+        enqueued from the autograd hooks, the compute stream waiting on them -- runs on a single GPU (the RCCL smoke test)."""
         self.all_params = [p for p in params if p.requires_grad]
-        self.group, self.overlap = group, overlap
+        self.group, self.overlap, self._single = group, overlap, bool(single_rank_collectives)
         self._limit = max(1, int(bucket_mb * (1 << 20)) // 4)
         self._events, self._host_exposed, self.steps = [], 0.0, 0
         self._scale, self._armed, self._trimmed = 1.0, False, False
@@ -144,7 +147,7 @@ class OverlappedGradAllReduce:
         self._work = [None] * self.num_buckets
 
     def _active(self):
-        return dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self._single)
 
     def prepare(self, local_samples, total_samples):
         """Before the backward: zero the buckets, point every .grad at its slice, reset the arrival counters."""

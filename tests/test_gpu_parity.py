@@ -11,12 +11,14 @@ fixtures' synthetic weights): fp32 device results have 24 significant bits, the 
 used where the arithmetic allows them (bit-exact cell records and indices, 2e-6 on transformed coordinates, 1e-6 between
 two device paths).
 
-The reference of every d(q) is the oracle with EXACT_POSE_GRADIENT (oracle/dpc_oracle.py): the reference's forward bit for bit,
-its gradient w.r.t. the pose quaternion with the sum over the points taken in fp64.  torch takes that sum in fp32, over a
-vector whose radial part (|.| ~ 100..1000) cancels afterwards: the reference's OWN d(q) scatters by up to the size of the rule
-around its exact value (1.6e-5 at N = 1300, |d(q)| ~ 1), so a device value can be held to the rule only against the exact sum.
-test_pose_gradient_against_the_reference_and_its_exact_sum keeps the raw reference in the picture: there the device must also
-be within the rule PLUS the reference's measured own deviation of the raw reference."""
+The reference of the fresh-seed d(q) checks is the oracle with EXACT_POSE_GRADIENT (oracle/dpc_oracle.py): the reference's forward
+bit for bit, its gradient w.r.t. the pose quaternion with the sum over the points taken in fp64.  torch takes that sum in fp32,
+over a vector whose radial part (|.| ~ 100..1000) cancels afterwards: the reference's OWN d(q) scatters by up to the size of the
+rule around its exact value (1.6e-5 at N = 1300, |d(q)| ~ 1), so a device value can be held to the rule only against the exact
+sum.  That oracle variant is pinned on CPU against the golden vectors (tests/test_oracle_golden.py::
+test_exact_pose_gradient_mode_is_pinned); the golden-vector tests here (F2, F6, F10) compare d(q) with the RAW reference's stored
+values; and test_pose_gradient_against_the_reference_and_its_exact_sum measures all three distances in the case that sat at the
+rule: device - exact (<= rule), device - raw (<= rule + the raw reference's own deviation), raw - exact."""
 import json
 import os
 
@@ -588,6 +590,49 @@ def test_fused_loss_does_not_hide_divergence(R, O):
     keep = [0, 1, 3]
     close(gq.grad[keep], cq.grad[keep], TOL, "NaN pose: dq of the other clouds")
     close(gp.grad[keep], cp.grad[keep], TOL, "NaN pose: dpc of the other clouds")
+
+
+@pytest.mark.parametrize("indexed", [False, True])
+def test_shared_point_sets_do_not_hide_divergence(R, O, indexed):
+    """The same for clouds that ADD into a shared point set's gradient (BASELINE config 3's layout): their contributions are
+    summed in 64-bit fixed point, and a NaN / Inf contribution has no integer to stand for it.  It must not come back as a
+    healthy-looking number: the set's gradient is NaN (the reference's float sums give NaN at the points the diverged cloud
+    touches; here the whole set is flagged -- the decoder above mixes every point into every weight either way), the other
+    sets keep the oracle's gradient, and the next clean call starts from zero again."""
+    S, reps, N, G = 2, 4, 700, 32
+    B = S * reps
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    pc = O.synth_inputs(S, N, G, 8810)[0]
+    _, q, s, _, _, _ = O.synth_inputs(B, 4, G, 8811)
+    gt = O.synth_inputs(B, 1, G, 8812)[3]
+    kern = R.smoothing_kernel(cfg, 1.0)
+    idx = R.point_dropout_indices(B, N, 0.6, torch.device("cuda"), torch.Generator(device="cuda").manual_seed(3)) if indexed else None
+
+    def run(scale):
+        gp, gq, gs = dev(pc, True), dev(q, True), dev(scale, True)
+        loss, _, _ = R.pointcloud_project_loss(cfg, gp, gq, None, None, kern, scaling_factor=gs, gt=dev(gt), num_candidates=1,
+                                               point_index=idx)
+        loss.backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), gp.grad.clone(), gq.grad.clone()
+
+    clean = run(s)
+    assert torch.isfinite(clean[0]) and torch.isfinite(clean[1]).all()
+    bad_s = s.clone()
+    bad_s[1] = float("nan")                       # cloud 1 of point set 0
+    cp, cq, cs = (x.clone().requires_grad_(True) for x in (pc, q, bad_s))
+    mat = cp.repeat_interleave(reps, dim=0)
+    if indexed:
+        mat = mat.gather(1, idx.long().cpu().unsqueeze(-1).expand(-1, -1, 3))
+    ref = O.pointcloud_project_fast(cfg, mat, cq, None, None, O.smoothing_kernel(cfg, 1.0), scaling_factor=cs)
+    (((ref["proj"] - gt) ** 2).sum() / B).backward()
+    assert bool(torch.isnan(cp.grad[0]).any()) and bool(torch.isfinite(cp.grad[1]).all())
+    loss, dpc, dq = run(bad_s)
+    assert bool(torch.isnan(loss))
+    assert bool(torch.isnan(dpc[0][torch.isnan(cp.grad[0]).cuda()]).all()), "a NaN contribution came back as a finite gradient"
+    close(dpc[1], cp.grad[1], TOL, "diverged neighbour set: dpc of the healthy set")
+    again = run(s)
+    assert all(torch.equal(a, b) for a, b in zip(again, clean)), "the poison word must start from zero again"
 
 
 def test_silhouette_loss_candidates(R, O, golden):
@@ -1512,6 +1557,23 @@ def test_device_schedule_follows_sigma_and_keep_count_under_replay(R, O):
     part = R.point_dropout_indices(B, Nsrc, (cap + 0.5) / Nsrc, d, gen(), n_live=sched.n_live)
     full = R.point_dropout_indices(B, Nsrc, 123.5 / Nsrc, d, gen())
     assert full.shape == (B, 123) and torch.equal(part[:, :123], full)
+    # the STAGE-LEVEL path under the same schedule (the lazy entries of the fused loss's output dict, and the fallback for
+    # Gaussians too long for the fused kernels): the dead slots of a row splat nothing there either
+    with torch.no_grad():
+        _, lazy, _ = R.pointcloud_project_loss(cfg, dev(pc), dev(q), None, None, k0, scaling_factor=dev(s), gt=ggt, num_candidates=K,
+                                               point_index=idx, schedule=sched)
+        fast = R.pointcloud_project_fast(cfg, dev(pc), dev(q), None, None, k0, scaling_factor=dev(s), point_index=idx, schedule=sched)
+        want = R.pointcloud_project_fast(cfg, dev(pc), dev(q), None, None, k0, scaling_factor=dev(s),
+                                         point_index=idx[:, :123].contiguous())
+        for name, got in (("staged (loss dict)", lazy), ("from the saved grid (plain dict)", fast)):
+            close(got["voxels"], want["voxels"], 1e-6, "n_live < capacity, %s: voxels" % name)
+            close(got["proj_depth"], want["proj_depth"], 1e-6, "n_live < capacity, %s: proj_depth" % name)
+            assert torch.equal(got["tr_pc"][:, :123], want["tr_pc"]) and bool((got["tr_pc"][:, 123:] == 2.0).all())
+        close(lazy["proj"], want["proj"], 1e-6, "n_live < capacity: proj")
+    with pytest.raises(ValueError):          # values that no longer fit the captured tap windows / rows are refused
+        sched.update(big[0], big[2], 100)
+    with pytest.raises(ValueError):
+        sched.update(k0[0], k0[2], cap + 1)
 
 
 @pytest.mark.parametrize("B,N,G,ksz,sig,K,reps", [(8, 3000, 64, 21, 0.64, 1, 1), (5, 700, 32, 11, 1.3, 1, 1), (3, 1500, 64, 21, 3.0, 1, 1),
@@ -1589,6 +1651,231 @@ def test_shared_sets_with_several_writers_are_bit_reproducible(R, O, K, reps, in
     rloss.backward()
     close(runs[0][1], cp.grad, TOL, "several writers: dpc (K=%d reps=%d)" % (K, reps))
     close(runs[0][2], cq.grad, TOL, "several writers: dq")
+
+
+@pytest.mark.parametrize("config", ["c2", "c4", "c5"])
+def test_benchmarked_step_plan_vs_oracle_at_full_size(R, O, config):
+    """THE entry point bench.py times by default -- dpc.render.project_loss_step(...).run(), one native call
+    (dpc_project_loss_step) on static buffers -- at the sizes it times, against the oracle directly (not through its
+    bit-identity with the autograd path at smaller sizes):
+      c2  B=32, N=8000, 64^3, sigma_rel 0.64, one pose candidate per sample: oracle on 3 of the 32 clouds
+      c4  the per-GPU shard of BASELINE configs[3]: 8 clouds x 16000 pts -> 128^3, sigma_rel 1.28: oracle on one cloud
+      c5  16 samples x K=8 candidates SHARING their sample's point set (point_replicas = 8, the layout bench.py --config c5
+          runs), min-of-K loss: winners from the device silhouettes, the oracle on one sample's 8 candidates
+    loss, proj, d(pc), d(q), d(s) under the parity rule; two runs of the plan bit for bit.
+    Reference call sequence: dpc/models/model_pc_to.py:239-282, 339-385, 410-440; dpc/run/train_to.py:122."""
+    S, K, N, G, sig = {"c2": (32, 1, 8000, 64, 0.64), "c4": (8, 1, 16000, 128, 1.28), "c5": (16, 8, 8000, 64, 0.64)}[config]
+    B = S * K
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=21)
+    kern = R.smoothing_kernel(cfg, sig)
+    d = torch.device("cuda")
+    pcS, _, sS, gtS, _, _ = O.synth_inputs(S, N, G, {"c2": 1234, "c4": 404, "c5": 505}[config])
+    q = O.synth_inputs(B, 1, G, 506)[1] if K > 1 else O.synth_inputs(S, N, G, {"c2": 1234, "c4": 404}[config])[1]
+    s = sS.repeat_interleave(K, dim=0)
+    plan = R.project_loss_step(cfg, kern, B, N, d, num_candidates=K, point_replicas=K)
+    args = [dev(pcS), dev(q), dev(s), dev(gtS)]
+    runs = []
+    for _ in range(2):
+        plan.run(*args)
+        torch.cuda.synchronize()
+        runs.append([x.clone() for x in (plan.loss, plan.proj, plan.dpc, plan.dq, plan.ds, plan.winner)])
+    for name, a, b in zip(("loss", "proj", "dpc", "dq", "ds", "winner"), *runs):
+        assert torch.equal(a, b), "%s step plan: %s differs between two runs" % (config, name)
+    loss, proj, dpc, dq, ds, win = runs[0]
+    assert torch.isfinite(proj).all() and torch.isfinite(dpc).all()
+    # loss and winners from the device's own silhouettes with the reference's formula (all samples)
+    rloss, rwin = O.proj_loss_pose_candidates(gtS, proj.double().cpu(), K)
+    assert np.array_equal(win.cpu().numpy(), rwin.numpy())
+    close(loss, rloss, TOL, "%s step plan: loss vs the reference formula on its silhouettes" % config)
+    # the oracle itself on a few samples (fp64 CPU: seconds per cloud)
+    for smp in {"c2": [0, 13, 31], "c4": [3], "c5": [5]}[config]:
+        sl = slice(smp * K, (smp + 1) * K)
+        cp = pcS[smp:smp + 1].clone().requires_grad_(True)
+        cq, cs = q[sl].clone().requires_grad_(True), s[sl].clone().requires_grad_(True)
+        ref = O.pointcloud_project_fast(cfg, cp.repeat_interleave(K, dim=0), cq, None, None, O.smoothing_kernel(cfg, sig),
+                                        scaling_factor=cs)
+        l1, w1 = O.proj_loss_pose_candidates(gtS[smp:smp + 1], ref["proj"], K)
+        (l1 / S).backward()                        # the batch loss divides by the S samples
+        assert w1.item() == int(win[smp])
+        tag = "%s step plan, sample %d: " % (config, smp)
+        close(proj[sl], ref["proj"], TOL, tag + "proj vs oracle")
+        close(dpc[smp:smp + 1], cp.grad, TOL, tag + "dpc vs oracle")
+        close(dq[sl], cq.grad, TOL, tag + "dq vs oracle")
+        close(ds[sl], cs.grad, TOL, tag + "ds vs oracle")
+    if K > 1:   # losing candidates: exact zeros in the small gradients
+        lose = torch.ones(B, dtype=torch.bool)
+        lose[torch.arange(S) * K + rwin] = False
+        assert dq[lose.cuda()].abs().max().item() == 0.0 and ds[lose.cuda()].abs().max().item() == 0.0
+
+
+def clamp_flip_analysis(O, cfg, sigma, pc, q, s, gt, reps, rel=1e-5, reach=4):
+    """Oracle side of test_drc_clamp_threshold_flip_is_bounded_and_explained (K = 1, shared point sets of `reps` clouds).
+    Returns a dict with
+      near      [k,4] (cloud, z, y, x) of the voxels whose occupancy lies within `rel` RELATIVE of eps or 1 - eps (drc.py:57)
+      touched   [S,N] bool: points of a set with a trilinear corner within `reach` voxels (Chebyshev) of such a voxel in one of
+                the set's clouds -- the only points the decision about that voxel can reach (the Gaussian's taps beyond
+                +-3 weigh < 1e-8 at sigma_rel 0.64, a point spreads over cell .. cell+1)
+      base      the un-nudged oracle: per-cloud d(points) [B,N,3], dq [B,4], ds [B,1], proj
+      variants  {cloud: [(bits, dpc_b [N,3], dq_b [4], ds_b [1]), ...]}: cloud b re-run alone with every assignment `bits`
+                of pass (1) / block (0) to its near voxels, forced through O.DRC_CLAMP_NUDGE
+    """
+    import itertools
+
+    B, S, N = q.shape[0], pc.shape[0], pc.shape[1]
+    G = cfg.vox_size
+    eps = cfg.drc_logsum_clip_val
+    kern = O.smoothing_kernel(cfg, sigma)
+    mat = pc.repeat_interleave(reps, dim=0).clone().requires_grad_(True)   # a leaf per cloud: every cloud's own contribution
+    cq, cs = q.clone().requires_grad_(True), s.clone().requires_grad_(True)
+    ref = O.pointcloud_project_fast(cfg, mat, cq, None, None, kern, scaling_factor=cs)
+    (((ref["proj"] - gt) ** 2).sum() / B).backward()
+    v = ref["voxels"].detach()[..., 0]
+    near = (((v - eps).abs() <= rel * eps) | ((v - (1.0 - eps)).abs() <= rel * (1.0 - eps))).nonzero()
+    tr = ref["tr_pc"].detach()
+    cell = torch.floor((tr + 0.5) * (G - 1.0)).long()
+    inside = ((tr >= -0.5) & (tr <= 0.5)).all(-1)
+    touched = torch.zeros(S, N, dtype=torch.bool)
+    for b, z, y, x in near.tolist():
+        c = cell[b] - torch.tensor([z, y, x])
+        hit = inside[b] & ((c >= -(reach + 1)) & (c <= reach)).all(-1)
+        touched[b // reps] |= hit
+    variants = {}
+    for b in sorted(set(near[:, 0].tolist())):
+        mine = [n for n in near.tolist() if n[0] == b]
+        variants[b] = []
+        for bits in itertools.product((0, 1), repeat=len(mine)):
+            nudge = torch.zeros(1, G if cfg.vox_size_z == -1 else cfg.vox_size_z, G, G, 1, dtype=torch.float64)
+            for (_, z, y, x), keep in zip(mine, bits):
+                val = v[b, z, y, x].item()
+                low = abs(val - eps) <= abs(val - (1.0 - eps))
+                th = eps if low else 1.0 - eps
+                inward = (1.0 + 1e-9) if low else (1.0 - 1e-9)          # just inside [eps, 1-eps] / just outside
+                nudge[0, z, y, x, 0] = th * (inward if keep else 2.0 - inward) - val
+            cp1, cq1, cs1 = (t[b:b + 1].detach().clone().requires_grad_(True) for t in (mat, q, s))
+            O.DRC_CLAMP_NUDGE = nudge
+            try:
+                r1 = O.pointcloud_project_fast(cfg, cp1, cq1, None, None, kern, scaling_factor=cs1)
+            finally:
+                O.DRC_CLAMP_NUDGE = None
+            (((r1["proj"] - gt[b:b + 1]) ** 2).sum() / B).backward()
+            assert (r1["proj"].detach() - ref["proj"].detach()[b:b + 1]).abs().max().item() < 1e-9   # the nudge is invisible forward
+            variants[b].append((bits, cp1.grad[0].double(), cq1.grad[0].double(), cs1.grad[0].double()))
+    return dict(near=near, touched=touched, variants=variants, proj=ref["proj"].detach(),
+                base=(mat.grad.double(), cq.grad.double(), cs.grad.double()))
+
+
+def test_drc_clamp_threshold_flip_is_bounded_and_explained(R, O):
+    """The reference's DRC clamp (dpc/util/drc.py:57, clamp(v, eps, 1 - eps)) switches a voxel's gradient on or off.  A voxel
+    whose fp64 occupancy lies within the fp32 Gaussian's rounding of eps can be decided the other way on the device; this input
+    (seed 9301, the one test_shared_sets_with_several_writers_are_bit_reproducible steers around) has two voxels within 1e-5
+    RELATIVE of eps, one of them at +7e-7.  Instead of avoiding the input, the event is pinned down:
+      * the near-threshold voxels are few and listed (oracle, fp64);
+      * every point OUTSIDE their reach (no trilinear corner within 4 voxels) has the oracle's gradient, by the rule;
+      * for each cloud holding such voxels, the device's d(points), d(q), d(s) equal -- by the rule -- the oracle re-run with
+        ONE assignment of pass / block to those voxels (forced through O.DRC_CLAMP_NUDGE, a 1e-10 nudge no forward value sees).
+    What stays outside the rule is reported, not hidden: the distance to the un-nudged oracle on the touched points."""
+    S, N, G, reps = 3, 2500, 64, 4
+    B = S * reps
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=21)
+    pc = O.synth_inputs(S, N, G, 9301)[0]
+    _, q, s, _, _, _ = O.synth_inputs(B, 4, G, 9400 + reps)
+    gt = O.synth_inputs(B, 1, G, 9500)[3]
+    A = clamp_flip_analysis(O, cfg, 0.64, pc, q, s, gt, reps)
+    near, touched = A["near"], A["touched"]
+    assert 1 <= len(near) <= 4, "expected a handful of near-threshold voxels in this input, found %d" % len(near)
+    assert 0 < int(touched.sum()) <= 0.03 * S * N, "the voxels' reach is a small neighbourhood (%d points)" % int(touched.sum())
+    gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+    loss, out, _ = R.pointcloud_project_loss(cfg, gp, gq, None, None, R.smoothing_kernel(cfg, 0.64), scaling_factor=gs, gt=dev(gt),
+                                             num_candidates=1)
+    loss.backward()
+    close(out["proj"], A["proj"], TOL, "clamp flip: proj")
+    dpc, dq, ds = gp.grad.double().cpu(), gq.grad.double().cpu(), gs.grad.double().cpu()
+    base_dpc, base_dq, base_ds = A["base"]
+    set_sum = lambda per_cloud: per_cloud.reshape(S, reps, N, 3).sum(1)
+    ref_dpc = set_sum(base_dpc)
+    scale = max(1.0, float(ref_dpc.abs().max()))
+    # (1) outside the reach of the near-threshold voxels: the oracle's gradient
+    close(dpc[~touched], ref_dpc[~touched], TOL, "clamp flip: dpc outside the near-threshold voxels' reach")
+    clean = [b for b in range(B) if b not in A["variants"]]
+    close(dq[clean], base_dq[clean], TOL, "clamp flip: dq of the clouds without such a voxel")
+    close(ds[clean], base_ds[clean], TOL, "clamp flip: ds of the clouds without such a voxel")
+    # (2) inside: one assignment of the voxels' pass bits explains the device, for every gradient of the cloud
+    import itertools
+    sets = sorted(set(b // reps for b in A["variants"]))
+    chosen = {}
+    for j in sets:
+        clouds = [b for b in A["variants"] if b // reps == j]
+        best = None
+        for combo in itertools.product(*[range(len(A["variants"][b])) for b in clouds]):
+            per_cloud = base_dpc[j * reps:(j + 1) * reps].clone()
+            errs = []
+            for b, vi in zip(clouds, combo):
+                bits, dpc_b, dq_b, ds_b = A["variants"][b][vi]
+                per_cloud[b - j * reps] = dpc_b
+                errs.append(float((dq[b] - dq_b).abs().max()) / max(1.0, float(base_dq.abs().max())))
+                errs.append(float((ds[b] - ds_b).abs().max()) / max(1.0, float(base_ds.abs().max())))
+            errs.append(float((dpc[j] - per_cloud.sum(0)).abs().max()) / scale)
+            if best is None or max(errs) < best[0]:
+                best = (max(errs), [A["variants"][b][vi][0] for b, vi in zip(clouds, combo)], per_cloud.sum(0))
+        chosen[j] = best
+        ERRORS.append(("clamp flip: gradients of point set %d under the explaining assignment %s (relative to the rule's scale)"
+                       % (j, best[1]), best[0], 1.0))
+        assert best[0] <= TOL, "no assignment of the near-threshold voxels explains the device gradients of set %d: %.3e" % (j, best[0])
+    # what the flip is worth, reported (NOT held to the rule: it is the explained event)
+    unexplained = float((dpc[touched] - ref_dpc[touched]).abs().max())
+    ERRORS.append(("clamp flip: dpc vs the UN-NUDGED oracle on the %d touched points (the explained event; not a bound)"
+                   % int(touched.sum()), unexplained, scale))
+    flipped = {j: c[1] for j, c in chosen.items() if any(0 in bits for bits in c[1])}
+    print("clamp flip: near-threshold voxels", near.tolist(), "assignments", {j: c[1] for j, c in chosen.items()},
+          "flipped on the device:", flipped, "distance to the un-nudged oracle on touched points %.3e" % unexplained)
+
+
+def test_pose_gradient_against_the_reference_and_its_exact_sum(R, O):
+    """The case that sat AT the parity rule in round 2 (K = reps = 8 shared sets, N = 1300, |d(q)| = 1.67).  The reference's own
+    d(q) -- torch sums the per-point terms of the first Hamilton product in fp32 (dpc/util/quaternion.py:69-86, 119-131) --
+    deviates from the same gradient summed exactly by about the size of the rule.  Both references stay in the picture:
+      * device vs the exact sum (oracle, EXACT_POSE_GRADIENT = True, pinned on CPU by
+        tests/test_oracle_golden.py::test_exact_pose_gradient_mode_is_pinned):  <= rule
+      * device vs the RAW reference (oracle default mode = the golden-pinned restatement):  <= rule + the raw reference's
+        measured own deviation from its exact sum
+    and all three numbers go into gpurun_out/parity_errors.json."""
+    K = reps = 8
+    S, N, G = 2, 1300, 32
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=11)
+    pc = O.synth_inputs(S, N, G, 5100 + K)[0]
+    _, q, s, _, _, _ = O.synth_inputs(S * reps, 4, G, 5200)
+    gt = O.synth_inputs(S, 1, G, 5300)[3]
+    refs = {}
+    try:
+        for exact in (False, True):
+            O.EXACT_POSE_GRADIENT = exact
+            cp, cq, cs = (x.clone().requires_grad_(True) for x in (pc, q, s))
+            out = O.pointcloud_project_fast(cfg, cp.repeat_interleave(reps, dim=0), cq, None, None, O.smoothing_kernel(cfg, 0.9),
+                                            scaling_factor=cs)
+            loss, win = O.proj_loss_pose_candidates(gt, out["proj"], K)
+            loss.backward()
+            refs[exact] = (out["proj"].detach(), cq.grad.double(), cp.grad.double(), win, cs.grad.double())
+    finally:
+        O.EXACT_POSE_GRADIENT = True   # what the module fixture set
+    assert torch.equal(refs[False][0], refs[True][0]), "the exact-sum mode must not change the reference's forward"
+    own = float((refs[False][1] - refs[True][1]).abs().max())
+    scale = max(1.0, float(refs[True][1].abs().max()))
+    gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+    loss, _, win = R.pointcloud_project_loss(cfg, gp, gq, None, None, R.smoothing_kernel(cfg, 0.9), scaling_factor=gs, gt=dev(gt),
+                                             num_candidates=K)
+    loss.backward()
+    assert np.array_equal(win.cpu().numpy(), refs[True][3].numpy())
+    err_exact = float((gq.grad.double().cpu() - refs[True][1]).abs().max())
+    err_raw = float((gq.grad.double().cpu() - refs[False][1]).abs().max())
+    ERRORS.append(("pose gradient: dq, device vs the reference's exact sum", err_exact, scale))
+    ERRORS.append(("pose gradient: dq, device vs the RAW reference (bound: rule + the reference's own deviation)", err_raw, scale))
+    ERRORS.append(("pose gradient: dq, the raw reference vs its own exact sum (not a device error)", own, scale))
+    assert err_exact <= TOL * scale, (err_exact, scale)
+    assert err_raw <= TOL * scale + own, (err_raw, own, scale)
+    assert own > 0.3 * TOL * scale, "the reference's fp32 summation noise was expected to be visible in this case (%.2e)" % own
+    close(gp.grad, refs[True][2], TOL, "pose gradient case: dpc")
+    close(gp.grad, refs[False][2], TOL, "pose gradient case: dpc vs the raw reference")
+    close(gs.grad, refs[False][4], TOL, "pose gradient case: ds vs the raw reference")
 
 
 def test_zz_error_report():

@@ -209,11 +209,19 @@ def test_captured_step_follows_the_dropout_schedule(f10):
     live, losses = [], []
     for _ in range(36):
         losses.append(float(replay(images, masks)))
-        live.append(int(step._schedule.n_live.item()))
+        live.append(int(step._captured_schedule.n_live.item()))
     want = [int(cfg.pc_num_points * R.get_dropout_prob(cfg, k)) for k in range(1, 37)]
     assert live == want, (live, want)
-    assert all(np.isfinite(losses)) and step.recaptures >= 1 and step._schedule.capacity >= want[-1]
+    assert all(np.isfinite(losses)) and step.recaptures >= 1 and step._captured_schedule.capacity >= want[-1]
     assert R.check_status() == 0
+    # the schedule is visible to loss() only WHILE a graph is captured: an eager call on the same object afterwards takes its
+    # keep-count from the step it is asked for, not from whatever the last replay left in device memory
+    assert step._schedule is None
+    _, out3 = step.loss(images, masks, global_step=3)
+    _, out30 = step.loss(images, masks, global_step=30)
+    torch.cuda.synchronize()
+    assert not torch.equal(out3["projs"], out30["projs"]), "eager calls at two steps of the schedule must differ"
+    assert int(step._captured_schedule.n_live.item()) == want[-1], "an eager call does not touch the captured schedule"
 
 
 @pytest.mark.gpu
@@ -310,6 +318,117 @@ def test_config3_captured_with_dropout_replays():
     assert all(np.isfinite(losses)) and step.global_step == before + 6
     assert all(torch.isfinite(p).all() for p in step.nets.parameters())
     assert len(set(losses)) == len(losses)
+
+
+def _c4_full_step_cfg():
+    """BASELINE configs[3] as worded, per rank (bench.py --config c4 --full-step): 8 objects x 1 view x 1 pose -> 8 clouds of
+    16000 points into 128^3, the decoder sized by the points (pc_decoder_to.py:20-21: 1024 -> 48000), sigma = 0.01 world
+    units (sigma_rel 1.28), no point dropout."""
+    from dpc.harness import chair_unsupervised
+
+    return chair_unsupervised(pc_point_dropout=1.0, pc_num_points=16000, vox_size=128, batch_size=8, step_size=1,
+                              pose_predict_num_candidates=1, pose_predictor_student=False, pc_relative_sigma=1.28,
+                              pc_relative_sigma_end=1.28)
+
+
+@pytest.mark.gpu
+def test_config4_full_training_step():
+    """BASELINE configs[3] as a TRAINING step on one rank's shard (forward -> get_loss -> backward -> step,
+    dpc/run/train_to.py:110-123) at full size: 8 images 128^2 -> encoder -> decoder 1024 -> 48000 -> 8 clouds x 16000 pts ->
+    128^3 -> silhouettes 128^2 -> loss -> backward -> Adam.  Everything finite, 57.9 M parameters receive a gradient, the
+    silhouettes / loss / winners of the step equal the renderer-only call on the same decoded points, and eight Adam steps
+    on one batch reduce the loss."""
+    import dpc.render as R
+    from dpc.harness import TrainStep, pooled_masks
+
+    cfg = _c4_full_step_cfg()
+    d = torch.device("cuda")
+    torch.manual_seed(0)
+    step = TrainStep(cfg, d, lr=1e-4)
+    gen = torch.Generator().manual_seed(77)
+    images = torch.rand(8, 3, 128, 128, generator=gen).to(d)
+    masks = (torch.rand(8, 1, 128, 128, generator=gen) > 0.5).float().to(d)
+    total, out = step.loss(images, masks)
+    assert out["points_1"].shape == (8, 16000, 3) and out["projs"].shape == (8, 128, 128, 1)
+    assert torch.isfinite(total) and torch.isfinite(out["projs"]).all()
+    # the renderer-only call on the same decoded points, poses and scales
+    kern = R.smoothing_kernel(cfg, 1.28)
+    gt = pooled_masks(masks, 128)
+    l2, o2, w2 = R.pointcloud_project_loss(cfg, out["points_1"].detach(), out["poses"].detach(), None, None, kern,
+                                           scaling_factor=out["scaling_factor"].detach(), gt=gt, num_candidates=1)
+    assert torch.equal(o2["proj"], out["projs"]) and torch.equal(w2, out["min_loss"])
+    assert torch.equal(l2, out["proj_loss"].detach())
+    plain = R.pointcloud_project_fast(cfg, out["points_1"].detach(), out["poses"].detach(), None, None, kern,
+                                      scaling_factor=out["scaling_factor"].detach())["proj"]
+    assert (plain - out["projs"]).abs().max().item() <= 1e-6
+    total.backward()
+    with_grad = [p for p in step.nets.parameters() if p.grad is not None]
+    assert all(torch.isfinite(p.grad).all() for p in with_grad)
+    assert 57e6 < sum(p.numel() for p in with_grad) < 59e6        # 232 MB of gradients per rank in the 8-GPU exchange
+    assert step.nets.decoder.pts_raw_fc.weight.shape == (48000, 1024)   # pc_decoder_to.py:20-21: sized by pc_num_points
+    step.optimizer.zero_grad(set_to_none=True)
+    losses = [float(step(images, masks)) for _ in range(9)]
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.gpu
+def test_rccl_gradient_exchange_on_one_gpu():
+    """RCCL itself, on the one GPU a test box has: init_process_group("nccl", world_size=1) -- librccl loads, a communicator
+    is built on the device -- and one full training step (tiny F10 networks, the real renderer) whose parameter gradients go
+    through OverlappedGradAllReduce with the collectives really issued (single_rank_collectives: an all-reduce over one rank
+    is an identity) from the autograd hooks.  The step's loss and every parameter after the update equal the step without
+    any exchange bit for bit; the exchange reports its buckets and that every one was reduced.
+    Reference loop: dpc/run/train_to.py:110-123 (single process; the exchange is what SURVEY.md 8(e) adds)."""
+    import socket
+
+    import torch.distributed as dist
+    from dpc.harness import TrainStep
+    from dpc.render.parallel import OverlappedGradAllReduce, global_mean_loss
+
+    cfg = Cfg(json.load(open(os.path.join(GOLDEN, "f10_config.json"))))
+    g = np.load(os.path.join(GOLDEN, "f10_full_step.npz"))
+    state = {k[len("state/"):]: torch.from_numpy(g[k]) for k in g.files if k.startswith("state/")}
+    d = torch.device("cuda", 0)
+    images, masks = torch.from_numpy(g["images"]).to(d), torch.from_numpy(g["masks"]).to(d)
+
+    def one_step(sync_factory):
+        torch.manual_seed(0)
+        np.random.seed(5)
+        step = TrainStep(cfg, d, lr=1e-3)
+        step.load_reference_state(state)
+        sync = sync_factory(step)
+        if sync is not None:
+            step.grad_sync, step.sync_samples = sync, (cfg.batch_size, cfg.batch_size)
+        loss = step(images, masks)
+        torch.cuda.synchronize()
+        return loss.clone(), [p.detach().clone() for p in step.nets.parameters()], sync
+
+    want_loss, want_params, _ = one_step(lambda step: None)
+    assert not dist.is_initialized()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0, device_id=d)
+    try:
+        assert dist.get_backend() == "nccl"
+        probe = torch.arange(8, dtype=torch.float32, device=d)
+        dist.all_reduce(probe)                    # a first collective on its own: RCCL builds its communicator here
+        torch.cuda.synchronize()
+        assert torch.equal(probe.cpu(), torch.arange(8, dtype=torch.float32))
+        loss, params, sync = one_step(lambda step: OverlappedGradAllReduce(step.nets.parameters(), bucket_mb=1,
+                                                                           single_rank_collectives=True))
+        assert sync.num_buckets >= 1 and sync.steps == 1
+        assert all(w is not None and w is not True for w in sync._work), "every bucket went through an RCCL all-reduce"
+        assert torch.equal(loss, want_loss)
+        for a, b in zip(params, want_params):
+            assert torch.equal(a, b), "a parameter differs after the step with the RCCL exchange"
+        mean = global_mean_loss(loss, cfg.batch_size)
+        torch.cuda.synchronize()
+        assert abs(float(mean) - float(loss)) <= 1e-6 * max(1.0, abs(float(loss)))
+    finally:
+        dist.destroy_process_group()
 
 
 def test_view_sampler_matches_reference():

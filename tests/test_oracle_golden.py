@@ -195,6 +195,51 @@ def test_chain(golden, name, sem):
         close(out["voxels_raw"].sum((2, 3)), g[sem + "_raw_zsum"].reshape(B, -1), 1e-10)
 
 
+@pytest.mark.parametrize("name", ["f6_chain_g32.npz", "f6_chain_g32_tf.npz", "f6_chain_g32_nos.npz",
+                                  "f6_chain_g32z16.npz", "f6_chain_c1_s3p0.npz", "f6_chain_c1_s0p64.npz"])
+def test_exact_pose_gradient_mode_is_pinned(golden, name):
+    """EXACT_POSE_GRADIENT = True is the variant every fresh-seed d(q) check of tests/test_gpu_parity.py and smoke() hold
+    the device to.  It is a custom autograd.Function, so it is pinned here against the SAME golden vectors as the default
+    mode: (i) the forward is the default mode's bit for bit (and therefore the reference's, to the 1e-12 of test_chain);
+    (ii) d(q) moves away from the reference's own by no more than the parity rule 1e-5 * max(1, max|dq|) -- the size of the
+    reference's fp32 summation noise over N points (measured on these fixtures: 4.4e-6 at |dq| 1.2 and N = 512 ...
+    9.2e-5 at |dq| 304 and N = 8000, i.e. 0.3-3.6 ppm of the scale); (iii) every other gradient (d(pc), d(s), d(t), d(f))
+    stays within 1e-6 * max(1, max|.|) (fp32 rounding of d(pc) in a different order; ds, dt, df identical).
+    Reference: dpc/util/quaternion.py:69-86, 110-132."""
+    g = golden(name)
+    cfg = _chain_cfg(name)
+    kern = O.smoothing_kernel(cfg, float(g["sigma_rel"]))
+    res = {}
+    assert O.EXACT_POSE_GRADIENT is False, "another test left the oracle in exact-sum mode"
+    try:
+        for exact in (False, True):
+            O.EXACT_POSE_GRADIENT = exact
+            pc, q = leaf(T(g["pc"])), leaf(T(g["q"]))
+            s = leaf(T(g["s"])) if "s" in g else None
+            t = leaf(T(g["t"])) if "t" in g else None
+            f = leaf(T(g["f"])) if "f" in g else None
+            out = O.pointcloud_project_fast(cfg, pc, q, t, None, kern, scaling_factor=s, focal_length=f)
+            (((out["proj"] - T(g["gt"])) ** 2).sum() / pc.shape[0]).backward()
+            res[exact] = dict(proj=out["proj"].detach(), tr_pc=out["tr_pc"].detach(), depth=out["proj_depth"].detach(),
+                              dpc=pc.grad, dq=q.grad, ds=None if s is None else s.grad, dt=None if t is None else t.grad,
+                              df=None if f is None else f.grad)
+    finally:
+        O.EXACT_POSE_GRADIENT = False
+    raw, exact = res[False], res[True]
+    for k in ("proj", "tr_pc", "depth"):
+        assert torch.equal(raw[k], exact[k]), "exact-sum mode changed the forward value of " + k
+    close(exact["proj"], g["smooth_proj"], 1e-12)
+    scale = lambda x: max(1.0, float(np.abs(np.asarray(x)).max()))
+    close(exact["dq"], g["smooth_dq"], 1e-5 * scale(g["smooth_dq"]))
+    close(exact["dpc"], g["smooth_dpc"], 1e-6 * scale(g["smooth_dpc"]))
+    for nm in ("ds", "dt", "df"):
+        if exact[nm] is not None:
+            close(exact[nm], g["smooth_" + nm], 1e-6 * scale(g["smooth_" + nm]))
+    # and the mode does something: the reference's own fp32 sum is visibly not the exact one at N = 8000
+    if "c1" in name:
+        assert (raw["dq"].double() - exact["dq"].double()).abs().max().item() > 1e-6
+
+
 def test_literal_cpu_call_matches_no_smoothing(golden):
     """What pointcloud_project_fast returns on a CPU-only host == the chain with the Gaussian skipped."""
     g, h = golden("f6_literal_call_g32.npz"), golden("f6_chain_g32.npz")
