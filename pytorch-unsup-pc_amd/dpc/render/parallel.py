@@ -111,6 +111,7 @@ class OverlappedGradAllReduce:
         self.group, self.overlap, self._single = group, overlap, bool(single_rank_collectives)
         self._limit = max(1, int(bucket_mb * (1 << 20)) // 4)
         self._events, self._host_exposed, self.steps = [], 0.0, 0
+        self.collectives_issued = 0      # all-reduces handed to the backend so far (0 in a world of one without the flag)
         self._scale, self._armed, self._trimmed = 1.0, False, False
         self._layout(self.all_params)
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.all_params]
@@ -167,6 +168,7 @@ class OverlappedGradAllReduce:
             flat.mul_(self._scale)
         if self._active():
             self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self.collectives_issued += 1
         else:
             self._work[bi] = True
 
