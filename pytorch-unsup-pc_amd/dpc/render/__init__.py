@@ -59,13 +59,33 @@ def _check_live_branches(cfg):
                                   "(dpc/util/drc.py:45,84-92)")
 
 
+_plain_geometries = {}   # Geometry objects of calls without a Gaussian, by their constants
+
+
 def _geometry(cfg, kernel=None, schedule=None):
+    """Per-call constants as a Geometry.  Geometry objects are immutable after construction and cache their own DpcParams
+    blocks and buffer sizes per call shape, so they are reused: one per (kernel list, grid, camera constants) -- kept on the
+    KernelList smoothing_kernel returned (a list of bare tensors, as a caller other than this package's smoothing_kernel
+    may pass, is converted on every call as before)."""
     D, H, W = _grid(cfg)
+    key = (D, H, W, _get(cfg, "camera_distance", 2.0), _get(cfg, "focal_length", 1.875), _get(cfg, "drc_logsum_clip_val", 1e-5),
+           _get(cfg, "max_depth", 10.0), id(schedule))
+    cache = kernel.geometries if isinstance(kernel, KernelList) else (_plain_geometries if kernel is None else None)
+    if cache is not None:
+        hit = cache.get(key)
+        if hit is not None and hit.schedule is schedule:
+            if kernel is not None and not _get(cfg, "pc_separable_gauss_filter", True):
+                _kernel_taps(cfg, kernel)   # raises
+            return hit
     kxy = kz = None
     if kernel is not None:
         kxy, kz = _kernel_taps(cfg, kernel)
-    return Geometry(D, H, W, kxy, kz, _get(cfg, "camera_distance", 2.0), _get(cfg, "focal_length", 1.875),
-                    _get(cfg, "drc_logsum_clip_val", 1e-5), _get(cfg, "max_depth", 10.0), schedule=schedule)
+    geom = Geometry(D, H, W, kxy, kz, key[3], key[4], key[5], key[6], schedule=schedule)
+    if cache is not None:
+        if len(cache) >= 16:
+            cache.clear()
+        cache[key] = geom
+    return geom
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -117,6 +137,8 @@ def _kernel_taps(cfg, kernel):
     if not _get(cfg, "pc_separable_gauss_filter", True):
         raise NotImplementedError("pc_separable_gauss_filter: false leaves `kernel` unbound in the reference "
                                   "(dpc/util/gauss_kernel.py:52-55)")
+    if isinstance(kernel, KernelList):      # what smoothing_kernel returned: its host taps travel with it
+        return kernel.taps
     host = lambda k: np.ascontiguousarray(k.detach().cpu().numpy() if isinstance(k, torch.Tensor) else k,
                                           dtype=np.float32).reshape(-1)
     if isinstance(kernel, (list, tuple)):
@@ -141,30 +163,61 @@ def gauss_kernel_1d(l, sig):
     return k / k.sum()
 
 
+class KernelList(list):
+    """The list of three separable kernels smoothing_kernel returns -- a plain list to every caller (the reference passes it
+    straight on to pointcloud_project_fast, dpc/models/model_pc_to.py:171-179, 262-265) that also carries what this package
+    derives from it on every call: the host tap arrays (`taps`) and the per-grid Geometry objects built from them
+    (`geometries`), so that a step pays for them once per kernel instead of once per call."""
+
+    __slots__ = ("taps", "geometries")
+
+    def __init__(self, items):
+        super().__init__(items)
+        kx, kz = (np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32).reshape(-1) for t in (items[0], items[2]))
+        self.taps = (kx, kz)
+        self.geometries = {}
+
+
 def separable_kernels(kernel):
     """[1,1,1,1,k], [1,1,1,k,1], [1,1,k,1,1] views of a 1-D kernel (dpc/util/gauss_kernel.py:27-32)."""
     n = kernel.shape[0]
-    return [kernel.reshape((1, 1, 1, 1, n)), kernel.reshape((1, 1, 1, n, 1)), kernel.reshape((1, 1, n, 1, 1))]
+    return KernelList([kernel.reshape((1, 1, 1, 1, n)), kernel.reshape((1, 1, 1, n, 1)), kernel.reshape((1, 1, n, 1, 1))])
+
+
+_kernel_cache = {}     # (taps, sigma, z taps, z sigma) -> KernelList; a training loop asks for the same sigma_rel every step
+                       # until the schedule moves it (model_pc_to.py:59-63), a benchmark loop for ever
 
 
 def smoothing_kernel(cfg, sigma):
     """The three separable kernels for pc_gauss_kernel_size and sigma (in voxels)
     (dpc/util/gauss_kernel.py:35-55).  With vox_size_z != vox_size the z kernel has length
-    floor(fsz*ratio)|1 and sigma*ratio -- what the reference intends; its own reshape at :49 raises."""
+    floor(fsz*ratio)|1 and sigma*ratio -- what the reference intends; its own reshape at :49 raises.
+    The result for a given (size, sigma) is memoised (the last few): the tensors are never modified by this package."""
     fsz = int(cfg.pc_gauss_kernel_size)
-    k = gauss_kernel_1d(fsz, sigma)
     vz = int(_get(cfg, "vox_size_z", -1))
+    fz, ratio = fsz, 1.0
     if vz != -1:
         ratio = vz / int(cfg.vox_size)
         fz = int(np.floor(fsz * ratio))
         if fz % 2 == 0:
             fz += 1
-        kz = k if (fz == fsz and ratio == 1.0) else gauss_kernel_1d(fz, sigma * ratio)
-        return [k.reshape((1, 1, 1, 1, fsz)), k.reshape((1, 1, 1, fsz, 1)), kz.reshape((1, 1, fz, 1, 1))]
-    if not _get(cfg, "pc_separable_gauss_filter", True):
+    elif not _get(cfg, "pc_separable_gauss_filter", True):
         raise NotImplementedError("pc_separable_gauss_filter: false leaves `kernel` unbound in the reference "
                                   "(dpc/util/gauss_kernel.py:52-55)")
-    return separable_kernels(k)
+    key = (fsz, float(sigma), fz, float(ratio))
+    hit = _kernel_cache.get(key)
+    if hit is not None:
+        return hit
+    k = gauss_kernel_1d(fsz, sigma)
+    if vz != -1:
+        kz = k if (fz == fsz and ratio == 1.0) else gauss_kernel_1d(fz, sigma * ratio)
+        out = KernelList([k.reshape((1, 1, 1, 1, fsz)), k.reshape((1, 1, 1, fsz, 1)), kz.reshape((1, 1, fz, 1, 1))])
+    else:
+        out = separable_kernels(k)
+    if len(_kernel_cache) >= 8:
+        _kernel_cache.pop(next(iter(_kernel_cache)))
+    _kernel_cache[key] = out
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------

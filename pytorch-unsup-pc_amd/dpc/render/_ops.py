@@ -15,7 +15,8 @@ from . import _native as N
 class Geometry:
     """Per-call constants: grid, camera, tap weights (host side)."""
 
-    __slots__ = ("D", "H", "W", "kxy", "kz", "camera_distance", "focal_length", "clip_val", "max_depth", "schedule")
+    __slots__ = ("D", "H", "W", "kxy", "kz", "camera_distance", "focal_length", "clip_val", "max_depth", "schedule",
+                 "_params", "_kptrs")
 
     def __init__(self, D, H, W, kxy=None, kz=None, camera_distance=2.0, focal_length=1.875, clip_val=1e-5,
                  max_depth=10.0, schedule=None):
@@ -32,6 +33,21 @@ class Geometry:
                 raise ValueError("smoothing kernels must have odd length <= %d, got %d" % (N.DPC_MAX_TAPS, k.size))
         self.camera_distance, self.focal_length = float(camera_distance), float(focal_length)
         self.clip_val, self.max_depth = float(clip_val), float(max_depth)
+        self._params = {}     # (B, Npts, replicas) -> Sized DpcParams of the calls without a point_index
+        self._kptrs = (None if self.kxy is None else self.kxy.ctypes.data, None if self.kz is None else self.kz.ctypes.data)
+
+    def sized(self, B, Npts, point_replicas=1, point_index=None, n_src=0):
+        """The DpcParams block of a call together with the buffer sizes the library derives from it (three native calls),
+        as a `Sized`; cached per call shape when there is no per-call pointer in it (no point_index)."""
+        if point_index is not None:
+            return Sized(self.params(B, Npts, point_replicas, point_index, n_src))
+        key = (B, Npts, point_replicas, n_src)
+        hit = self._params.get(key)
+        if hit is None:
+            if len(self._params) >= 32:
+                self._params.clear()
+            hit = self._params[key] = Sized(self.params(B, Npts, point_replicas, None, n_src))
+        return hit
 
     def params(self, B, Npts, point_replicas=1, point_index=None, n_src=0):
         """point_index: int32 device tensor [B,Npts] (kept alive by the caller for the duration of the call) selecting
@@ -48,8 +64,21 @@ class Geometry:
                            None if sch is None or self.kz is None else sch.taps_z.data_ptr())
 
     def kern_ptrs(self):
-        return (None if self.kxy is None else self.kxy.ctypes.data_as(ctypes.c_void_p),
-                None if self.kz is None else self.kz.ctypes.data_as(ctypes.c_void_p))
+        """Host addresses of the tap arrays (plain ints / None: the argtypes of the bindings take them as void*)."""
+        return self._kptrs
+
+
+class Sized:
+    """A DpcParams block, a reference to it for the calls, and the sizes of the buffers a call with it needs."""
+
+    __slots__ = ("P", "ref", "wpp", "cells_bytes", "ws_bytes")
+
+    def __init__(self, P):
+        L = N.lib()
+        self.P, self.ref = P, ctypes.byref(P)
+        self.wpp = L.dpc_mask_words_per_plane(self.ref)
+        self.cells_bytes = max(L.dpc_cells_bytes(self.ref), 1)
+        self.ws_bytes = max(L.dpc_workspace_bytes(self.ref), 1)
 
 
 _status = {}
@@ -133,7 +162,45 @@ def taps_bucket(k):
 
 
 def _f32(t):
-    return None if t is None else t.detach().to(torch.float32).contiguous()
+    if t is None:
+        return None
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t.detach()
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _dp(t):
+    """Device address of a tensor as a plain int (None -> NULL): the bindings' argtypes turn it into a void*."""
+    return None if t is None else t.data_ptr()
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def _stream(dev):
+    """torch's current HIP stream of `dev` as an address (the raw getter skips building a Stream object per call)."""
+    if _raw_stream is not None:
+        return _raw_stream(dev.index if dev.index is not None else torch.cuda.current_device())
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
+class _on:
+    """`with torch.cuda.device(dev)` only when `dev` is not the current device already (the guard costs ~10 us of host time
+    per call; a training process sits on its one device)."""
+
+    __slots__ = ("guard",)
+
+    def __init__(self, dev):
+        self.guard = None if (dev.index is None or dev.index == torch.cuda.current_device()) else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.guard is not None:
+            self.guard.__enter__()
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            return self.guard.__exit__(*exc)
+        return False
 
 
 def _replicas(pc, q):
@@ -166,12 +233,16 @@ def _meta(t):
 def _small(dsmall, col, width, B):
     """Dense [B,width] view of one gradient block of the small-gradient buffer (contiguous: autograd takes it
     without cloning)."""
-    return dsmall[col * B:(col + width) * B].view(B, width)
+    return dsmall.as_strided((B, width), (width, 1), col * B)   # one op instead of a slice and a view
 
 
 def _like_input(grad, meta):
     """Gradients arrive in the input's dtype and shape, like autograd's would."""
-    return None if grad is None or meta is None else grad.to(meta[0]).reshape(meta[1])
+    if grad is None or meta is None:
+        return None
+    if grad.dtype is meta[0] and tuple(grad.shape) == meta[1]:
+        return grad
+    return grad.to(meta[0]).reshape(meta[1])
 
 
 def _zero_grads(metas, dev):
@@ -246,19 +317,18 @@ class ProjectFused(torch.autograd.Function):
         idx = _index32(point_index, pc32, q32)
         B, reps = q32.shape[0], _replicas(pc32, q32)
         Npts = pc32.shape[1] if idx is None else idx.shape[1]
-        P = geom.params(B, Npts, reps, idx, pc32.shape[1])
-        wpp = L.dpc_mask_words_per_plane(ctypes.byref(P))
+        Z = geom.sized(B, Npts, reps, idx, pc32.shape[1])
         grid_wh = torch.empty((B, geom.D, geom.H, geom.W), dtype=torch.float32, device=dev)
-        mask = torch.empty((B, geom.D, wpp), dtype=torch.int64, device=dev)
-        cells = _new_cells(P, dev)
+        mask = torch.empty((B, geom.D, Z.wpp), dtype=torch.int64, device=dev)
+        cells = torch.empty((Z.cells_bytes,), dtype=torch.uint8, device=dev)
         proj = torch.empty((B, geom.H, geom.W, 1), dtype=torch.float32, device=dev)
         trans = torch.empty((B, geom.H, geom.W), dtype=torch.float32, device=dev)
         kxy, kz = geom.kern_ptrs()
-        with torch.cuda.device(dev):
-            rc = L.dpc_project_fwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
-                                   None, N.ptr(cells), None, N.ptr(grid_wh), None, N.ptr(mask), N.ptr(proj), N.ptr(trans),
-                                   N.stream_ptr(dev))
-        N.check(rc, "dpc_project_fwd")
+        with _on(dev):
+            rc = L.dpc_project_fwd(Z.ref, _dp(pc32), _dp(q32), _dp(t32), _dp(f32), _dp(s32), kxy, kz,
+                                   None, _dp(cells), None, _dp(grid_wh), None, _dp(mask), _dp(proj), _dp(trans), _stream(dev))
+        if rc != 0:
+            N.check(rc, "dpc_project_fwd")
         ctx.geom = geom
         ctx.inputs = tuple(_meta(x) for x in (pc, q, t, f, s))
         empty = pc32.new_empty(0)
@@ -282,20 +352,20 @@ class ProjectFused(torch.autograd.Function):
         dev = pc32.device
         L = N.lib()
         B, reps = q32.shape[0], _replicas(pc32, q32)
-        P = geom.params(B, ctx.npts, reps, cells if ctx.indexed else None, pc32.shape[1])  # the backward reads the source
+        Z = geom.sized(B, ctx.npts, reps, cells if ctx.indexed else None, pc32.shape[1])  # the backward reads the source
         # index out of the binned records; any non-NULL pointer says "dpc is per stored set, accumulate"
-        dproj32 = (torch.zeros((B, geom.H, geom.W), dtype=torch.float32, device=dev) if dproj is None
-                   else dproj.detach().to(torch.float32).contiguous())
-        dgrid32 = None if dgrid is None else dgrid.detach().to(torch.float32).contiguous()
+        dproj32 = torch.zeros((B, geom.H, geom.W), dtype=torch.float32, device=dev) if dproj is None else _f32(dproj)
+        dgrid32 = _f32(dgrid)
         dpc = torch.zeros_like(pc32) if (reps > 1 or ctx.indexed) else torch.empty_like(pc32)  # clouds add into a shared gradient
         dsmall = torch.empty((N.DPC_SMALL_COLS * B,), dtype=torch.float32, device=dev)
-        ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
+        ws = torch.empty((Z.ws_bytes,), dtype=torch.uint8, device=dev)
         kxy, kz = geom.kern_ptrs()
-        with torch.cuda.device(dev):
-            rc = L.dpc_project_bwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
-                                   N.ptr(cells), N.ptr(grid_wh), N.ptr(mask), N.ptr(trans), N.ptr(dproj32), N.ptr(dgrid32),
-                                   N.ptr(dpc), N.ptr(dsmall), N.ptr(ws), N.stream_ptr(dev))
-        N.check(rc, "dpc_project_bwd")
+        with _on(dev):
+            rc = L.dpc_project_bwd(Z.ref, _dp(pc32), _dp(q32), _dp(t32), _dp(f32), _dp(s32), kxy, kz,
+                                   _dp(cells), _dp(grid_wh), _dp(mask), _dp(trans), _dp(dproj32), _dp(dgrid32),
+                                   _dp(dpc), _dp(dsmall), _dp(ws), _stream(dev))
+        if rc != 0:
+            N.check(rc, "dpc_project_bwd")
         pc, q, t, f, s = ctx.inputs
         return (_like_input(dpc, pc), _like_input(_small(dsmall, N.COL_DQ, 4, B), q),
                 _like_input(_small(dsmall, N.COL_DT, 3, B), t) if has_t else None,
@@ -337,30 +407,30 @@ class ProjectLossFused(torch.autograd.Function):
             ctx.mark_non_differentiable(proj, winner)
             return torch.zeros((), dtype=torch.float32, device=dev), proj, winner
         ctx.empty = False
-        P = geom.params(B, Npts, reps, idx, pc32.shape[1])
-        wpp = L.dpc_mask_words_per_plane(ctypes.byref(P))
+        Z = geom.sized(B, Npts, reps, idx, pc32.shape[1])
         f32e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
         grid_wh, proj, trans = f32e(B, geom.D, geom.H, geom.W), f32e(B, geom.H, geom.W, 1), f32e(B, geom.H, geom.W)
         sse, loss = f32e(B), torch.empty((), dtype=torch.float32, device=dev)
         sse_tiles = f32e(B, (geom.H * geom.W + 255) // 256)   # per-tile partials of the unfused ray march (fixed-order sum)
-        mask = torch.empty((B, geom.D, wpp), dtype=torch.int64, device=dev)
+        mask = torch.empty((B, geom.D, Z.wpp), dtype=torch.int64, device=dev)
         winner = torch.empty((S,), dtype=torch.int32, device=dev)
-        cells = _new_cells(P, dev)
+        cells = torch.empty((Z.cells_bytes,), dtype=torch.uint8, device=dev)
         # backward buffers handed to the forward so it can run the column half of the backward right away -- only when a
         # backward can follow (grad mode is always off INSIDE forward(): the caller passes what it saw outside)
         want_grad = want_grad and any(x is not None and x.requires_grad for x in (pc, q, t, f, s))
         ws = dsmall = None
         if want_grad and K == 1:
-            ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
+            ws = torch.empty((Z.ws_bytes,), dtype=torch.uint8, device=dev)
             dsmall = f32e(N.DPC_SMALL_COLS * B)
         fused = ctypes.c_int(0)
         kxy, kz = geom.kern_ptrs()
-        with torch.cuda.device(dev):
-            rc = L.dpc_project_loss_fwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
-                                        N.ptr(gt32), K, None, N.ptr(cells), N.ptr(grid_wh), N.ptr(mask), N.ptr(proj),
-                                        N.ptr(trans), N.ptr(sse), N.ptr(sse_tiles), N.ptr(loss), N.ptr(winner), N.ptr(ws), N.ptr(dsmall),
-                                        ctypes.byref(fused), N.stream_ptr(dev))
-        N.check(rc, "dpc_project_loss_fwd")
+        with _on(dev):
+            rc = L.dpc_project_loss_fwd(Z.ref, _dp(pc32), _dp(q32), _dp(t32), _dp(f32), _dp(s32), kxy, kz,
+                                        _dp(gt32), K, None, _dp(cells), _dp(grid_wh), _dp(mask), _dp(proj),
+                                        _dp(trans), _dp(sse), _dp(sse_tiles), _dp(loss), _dp(winner), _dp(ws), _dp(dsmall),
+                                        ctypes.byref(fused), _stream(dev))
+        if rc != 0:
+            N.check(rc, "dpc_project_loss_fwd")
         ctx.geom, ctx.K, ctx.fused = geom, K, bool(fused.value)
         ctx.inputs = tuple(_meta(x) for x in (pc, q, t, f, s))
         empty = pc32.new_empty(0)
@@ -384,21 +454,22 @@ class ProjectLossFused(torch.autograd.Function):
         t32, f32, s32 = (t32 if has_t else None), (f32 if has_f else None), (s32 if has_s else None)
         geom, dev, L = ctx.geom, pc32.device, N.lib()
         B, reps = q32.shape[0], _replicas(pc32, q32)
-        P = geom.params(B, ctx.npts, reps, cells if ctx.indexed else None, pc32.shape[1])  # see ProjectFused.backward
+        Z = geom.sized(B, ctx.npts, reps, cells if ctx.indexed else None, pc32.shape[1])  # see ProjectFused.backward
         dl = dloss.detach().to(torch.float32).reshape(())
         dpc = torch.zeros_like(pc32) if (reps > 1 or ctx.indexed) else torch.empty_like(pc32)  # clouds add into a shared gradient
         # a FRESH block for dq / ds / dt / df on every call: k_gather_hw writes (never accumulates) them, and a block kept
         # across calls would alias the .grad tensors autograd took over from an earlier backward through this same forward
         out_small = torch.empty((N.DPC_SMALL_COLS * B,), dtype=torch.float32, device=dev)
         if not ctx.fused:
-            ws = torch.empty((max(L.dpc_workspace_bytes(ctypes.byref(P)), 1),), dtype=torch.uint8, device=dev)
+            ws = torch.empty((Z.ws_bytes,), dtype=torch.uint8, device=dev)
         kxy, kz = geom.kern_ptrs()
-        with torch.cuda.device(dev):
-            rc = L.dpc_project_loss_bwd(ctypes.byref(P), N.ptr(pc32), N.ptr(q32), N.ptr(t32), N.ptr(f32), N.ptr(s32), kxy, kz,
-                                        N.ptr(cells), N.ptr(grid_wh), N.ptr(mask), N.ptr(proj), N.ptr(trans), N.ptr(gt32),
-                                        ctx.K, N.ptr(winner), N.ptr(dl), int(ctx.fused), N.ptr(dpc), N.ptr(out_small),
-                                        N.ptr(ws), N.stream_ptr(dev))
-        N.check(rc, "dpc_project_loss_bwd")
+        with _on(dev):
+            rc = L.dpc_project_loss_bwd(Z.ref, _dp(pc32), _dp(q32), _dp(t32), _dp(f32), _dp(s32), kxy, kz,
+                                        _dp(cells), _dp(grid_wh), _dp(mask), _dp(proj), _dp(trans), _dp(gt32),
+                                        ctx.K, _dp(winner), _dp(dl), int(ctx.fused), _dp(dpc), _dp(out_small),
+                                        _dp(ws), _stream(dev))
+        if rc != 0:
+            N.check(rc, "dpc_project_loss_bwd")
         pc, q, t, f, s = ctx.inputs
         return (_like_input(dpc, pc), _like_input(_small(out_small, N.COL_DQ, 4, B), q),
                 _like_input(_small(out_small, N.COL_DT, 3, B), t) if has_t else None,
