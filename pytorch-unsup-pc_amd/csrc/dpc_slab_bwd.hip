@@ -62,14 +62,21 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     }
     return;
   }
-  const int nzp = min(Zs + 1, D - z0);  // planes present (cell layers + halo)
+  // Rolling workgroups walk their layers in ALTERNATING directions: slab x walks z0 -> z0+roll-1, its neighbour x+1 walks
+  // z0'+roll-1 -> z0'.  The plane two neighbours share (z0' = z0+roll: the last halo of one, the first plane of the other) is
+  // then read by both at the same moment -- the end of their walks, or the start -- so one of them finds it in the XCD's L2
+  // (all slabs of a cloud run on one XCD) instead of each fetching it from memory 30 us apart: the rolling backward read
+  // 1.42 x its algorithmic bytes from HBM in round 3 (profiles/r03_rocprof_summary_c4.json).
+  const bool down = kRolls && (bk.x & 1);
+  const int zfirst = down ? min(z0 + roll, D) - 1 : z0;   // the first layer this workgroup gathers
+  const int nzp = min(Zs + 1, D - zfirst);  // planes present (cell layers + halo)
   const int tid = threadIdx.x, nthr = blockDim.x;
   // camera inputs and the upstream scalar: requested now, first used after the slab is in LDS
   const CameraRaw cam_raw = load_camera_raw(P, q, t, f, b);
   const float upstream = (la.scale_in_gather && la.dloss != nullptr) ? *la.dloss : 1.0f;
   const int wpp = (HW + 63) / 64;
-  const float* src = dT + ((size_t)b * D + z0) * HW;
-  const uint64_t* mrow = mask + ((size_t)b * D + z0) * wpp;
+  const float* src = dT + ((size_t)b * D + zfirst) * HW;
+  const uint64_t* mrow = mask + ((size_t)b * D + zfirst) * wpp;
   float* red;
 
   if constexpr (GS > 0) {
@@ -77,7 +84,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     using Geo = BwdGeo<GS, RB, NPL>;
     red = slab + ((Geo::slab_floats(NPL) + 3) / 4) * 4;
     RecordRange rr{0, 0};
-    if (cells.nblk <= DPC_WAVE) rr = load_record_range(cells, b, z0, min(z0 + Zs, D));  // in flight under the H-pass
+    if (cells.nblk <= DPC_WAVE) rr = load_record_range(cells, b, zfirst, min(zfirst + Zs, D));  // in flight under the H-pass
     const uint32_t* mask32 = reinterpret_cast<const uint32_t*>(mrow);
     DPC_STAMP(8);
     for (int i = tid; i < (NPL * GS + 1) * (Geo::PAD / 4); i += Geo::NT) {  // zero the row pads (W-pass halo)
@@ -170,38 +177,65 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   // (Requesting a thread's NEXT record and point before it works on the current one -- so that the second pass over a slab
   // with more records than threads starts with its loads answered -- measured 0.3-0.5 us slower: the pass is bound by its
   // arithmetic, 2.1-2.7 us per pass of four waves per SIMD, not by the two dependent loads in front of it.)
+  // One (z, y) row of a point's cell: the adjoint W pass at its two x corners, masked (GS > 0, RB > 0 only).
+  auto corner_row = [&](const Cell& c, int k, int j, float& o0, float& o1) {
+    if constexpr (GS > 0 && RB > 0) {
+      using Geo = BwdGeo<GS, RB, ZS + 1>;
+      const uint32_t* mlds = reinterpret_cast<const uint32_t*>(red + kRedMask);
+      o0 = o1 = 0.f;
+      if ((c.iz + k < D) && (c.iy + j < GS)) {
+        const int plane = kRolls ? ((c.iz - zfirst + k) & 1) : (c.iz - z0 + k);  // rolling: plane z lives in buffer (z - zfirst) & 1
+        const int row = plane * GS + c.iy + j;
+        const float* rp = slab + row * Geo::WP + Geo::PAD + c.ix - RB;  // x = ix-RB .. ix+1+RB, pads are zero
+        float v[2 * RB + 2];
+#pragma unroll
+        for (int i = 0; i < 2 * RB + 2; ++i) v[i] = rp[i];
+        float o[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          float acc = 0.f;
+#pragma unroll
+          for (int tp = 0; tp < 2 * RB + 1; ++tp) acc = fmaf(taps_adj.w[tp], v[e + tp], acc);
+          const int x = c.ix + e;
+          const bool pass = x < GS && ((mlds[row * (GS / 32) + (x >> 5)] >> (x & 31)) & 1u);
+          o[e] = pass ? acc : 0.f;
+        }
+        o0 = o[0]; o1 = o[1];
+      }
+    }
+  };
+  // The rest of a point's backward, from its grid-coordinate gradient on: transform backward, camera sums, d(point).
+  auto finish_point = [&](const int4 pt, float dgz, float dgy, float dgx) {
+    const int i = pt.w;
+    dgz *= upstream; dgy *= upstream; dgx *= upstream;  // 1 unless dT was produced by the forward for dloss = 1
+    const float px = __int_as_float(pt.x), py = __int_as_float(pt.y), pz = __int_as_float(pt.z);
+    const Projected o = project_point(cam, px, py, pz);
+    float dpx, dpy, dpz;
+    project_point_bwd(cam, o, px, py, pz, dgz * (float)(D - 1), dgy * (float)(H - 1), dgx * (float)(W - 1), dpx, dpy, dpz, g);
+    if (shared_points && !single_writer) {
+      // several clouds add into this point set's gradient: 64-bit fixed-point adds (exact, so the sum does not depend on
+      // who arrives first); k_fixed_to_dpc turns the sums into floats behind this launch
+      if (grad_fits_fixed(dpx, dpy, dpz)) {
+        unsigned long long* acc = dpc_fixed + ((size_t)(b / reps) * Nset + i) * 3;
+        atomicAdd(acc + 0, grad_to_fixed(dpx)); atomicAdd(acc + 1, grad_to_fixed(dpy)); atomicAdd(acc + 2, grad_to_fixed(dpz));
+      } else {   // NaN / Inf / out of range: poison the set (dpc_kernels.h), k_fixed_to_dpc writes NaN
+        atomicOr(reinterpret_cast<unsigned int*>(dpc_fixed + (size_t)(P.B / reps) * Nset * 3) + b / reps, 1u);
+      }
+    } else {
+      // (ordinary stores: these 12-byte scattered writes cost the kernel 4 us when written through)
+      dcloud[3 * i + 0] = dpx; dcloud[3 * i + 1] = dpy; dcloud[3 * i + 2] = dpz;
+    }
+  };
   auto gather = [&](const PointRec& rec, const int4* aux) {
     const int4 pt = *aux;  // {px, py, pz, original index}: one 16-byte load, issued next to the record's
-    const int i = pt.w;
     const Cell c = cell_from_record(rec);
     float cv[2][2][2];
     if constexpr (GS > 0 && RB > 0) {
       // adjoint W-pass evaluated right here, at the two x corners of each of the four (z,y) rows, then masked
-      using Geo = BwdGeo<GS, RB, ZS + 1>;
-      const uint32_t* mlds = reinterpret_cast<const uint32_t*>(red + kRedMask);
 #pragma unroll
       for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          cv[k][j][0] = cv[k][j][1] = 0.f;
-          if ((c.iz + k < D) && (c.iy + j < GS)) {
-            const int plane = kRolls ? ((c.iz - z0 + k) & 1) : (c.iz - z0 + k);  // rolling: plane z lives in buffer (z - z0) & 1
-            const int row = plane * GS + c.iy + j;
-            const float* rp = slab + row * Geo::WP + Geo::PAD + c.ix - RB;  // x = ix-RB .. ix+1+RB, pads are zero
-            float v[2 * RB + 2];
-#pragma unroll
-            for (int i = 0; i < 2 * RB + 2; ++i) v[i] = rp[i];
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-              float acc = 0.f;
-#pragma unroll
-              for (int tp = 0; tp < 2 * RB + 1; ++tp) acc = fmaf(taps_adj.w[tp], v[e + tp], acc);
-              const int x = c.ix + e;
-              const bool pass = x < GS && ((mlds[row * (GS / 32) + (x >> 5)] >> (x & 31)) & 1u);
-              cv[k][j][e] = pass ? acc : 0.f;
-            }
-          }
-        }
+        for (int j = 0; j < 2; ++j) corner_row(c, k, j, cv[k][j][0], cv[k][j][1]);
     } else {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
@@ -222,28 +256,15 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
         dgy += (cv[a][1][e] - cv[a][0][e]) * c.wz[a] * c.wx[e];
         dgx += (cv[a][e][1] - cv[a][e][0]) * c.wz[a] * c.wy[e];
       }
-    dgz *= upstream; dgy *= upstream; dgx *= upstream;  // 1 unless dT was produced by the forward for dloss = 1
-    const float px = __int_as_float(pt.x), py = __int_as_float(pt.y), pz = __int_as_float(pt.z);
-    const Projected o = project_point(cam, px, py, pz);
-    float dpx, dpy, dpz;
-    project_point_bwd(cam, o, px, py, pz, dgz * (float)(D - 1), dgy * (float)(H - 1), dgx * (float)(W - 1), dpx, dpy, dpz, g);
-    if (shared_points && !single_writer) {
-      // several clouds add into this point set's gradient: 64-bit fixed-point adds (exact, so the sum does not depend on
-      // who arrives first); k_fixed_to_dpc turns the sums into floats behind this launch
-      if (grad_fits_fixed(dpx, dpy, dpz)) {
-        unsigned long long* acc = dpc_fixed + ((size_t)(b / reps) * Nset + i) * 3;
-        atomicAdd(acc + 0, grad_to_fixed(dpx)); atomicAdd(acc + 1, grad_to_fixed(dpy)); atomicAdd(acc + 2, grad_to_fixed(dpz));
-      } else {   // NaN / Inf / out of range: poison the set (dpc_kernels.h), k_fixed_to_dpc writes NaN
-        atomicOr(reinterpret_cast<unsigned int*>(dpc_fixed + (size_t)(P.B / reps) * Nset * 3) + b / reps, 1u);
-      }
-    } else {
-      // (ordinary stores: these 12-byte scattered writes cost the kernel 4 us when written through)
-      dcloud[3 * i + 0] = dpx; dcloud[3 * i + 1] = dpy; dcloud[3 * i + 2] = dpz;
-    }
+    finish_point(pt, dgz, dgy, dgx);
   };
+  // (Rolling steps hold ~N/D records for 1024 threads -- c4: 125.  Four threads per record, one per (z, y) row, their partial
+  // sums added over DPP quad permutes, measured SLOWER: k_gather_hw<128,1,8> 37.9 -> 40.1 us.  The step is a chain of phases
+  // -- plane load, H pass, barrier, gather, barrier -- of which the gather's arithmetic is the smallest part;
+  // profiles/r04_patches/, profiles/LAB_NOTES.md.)
   if (!DPC_ABL(10)) {
     if (GS > 0 && cells.nblk <= DPC_WAVE) for_each_record_flat(cells, b, reinterpret_cast<const int*>(red + kRedTab), gather);
-    else for_each_record(cells, b, z0, min(z0 + Zs, D), gather);
+    else for_each_record(cells, b, zfirst, min(zfirst + Zs, D), gather);
   }
   if constexpr (kRolls) {
     using Geo = BwdGeo<GS, RB, 2>;
@@ -252,19 +273,22 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     uint32_t* mlds = reinterpret_cast<uint32_t*>(red + kRedMask);
     int* tab = reinterpret_cast<int*>(red + kRedTab);
     const bool flat = cells.nblk <= DPC_WAVE;
-    for (int l = 1; l < roll && z0 + l < D; ++l) {
-      __syncthreads();  // layer l-1 is gathered: plane z0+l-1 (buffer (l-1)&1 == (l+1)&1) and the record table are free
-      const int buf = (l + 1) & 1;
-      const bool present = z0 + l + 1 < D;
+    for (int l = 1; l < roll && (down ? zfirst - l >= z0 : z0 + l < D); ++l) {
+      __syncthreads();  // the last layer is gathered: the plane it does not share with this one, and the record table, are free
+      const int zl = down ? zfirst - l : z0 + l;      // this step's layer: planes zl and zl + 1
+      const int znew = down ? zl : zl + 1;            // ... of which this one is not in LDS yet
+      const int buf = (znew - zfirst) & 1;            // plane z lives in buffer (z - zfirst) & 1: the freed one
+      const bool present = znew < D;
       RecordRange rr{0, 0};
-      if (flat) rr = load_record_range(cells, b, z0 + l, z0 + l + 1);
+      if (flat) rr = load_record_range(cells, b, zl, zl + 1);
+      const ptrdiff_t rel = (ptrdiff_t)znew - zfirst; // planes relative to the pointers of the first step
       uint32_t mreg[MPT1];
 #pragma unroll
       for (int it = 0; it < MPT1; ++it) {
         const int w = tid + it * Geo::NT;
-        mreg[it] = (w < MW1 && present) ? mask32[(size_t)(l + 1) * MW1 + w] : 0u;
+        mreg[it] = (w < MW1 && present) ? mask32[rel * MW1 + w] : 0u;
       }
-      hpass_global<Geo, GS, RB, 1>(src + (size_t)(l + 1) * HW, present ? 1 : 0, taps_adj, [&](int, int y, int x, f32x2 val) {
+      hpass_global<Geo, GS, RB, 1>(src + rel * HW, present ? 1 : 0, taps_adj, [&](int, int y, int x, f32x2 val) {
         *reinterpret_cast<f32x2*>(slab + Geo::at(buf, y, x)) = val;
       });
 #pragma unroll
@@ -275,7 +299,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
       if (flat) finish_record_table(rr, tab);
       __syncthreads();
       if (flat) for_each_record_flat(cells, b, tab, gather);
-      else for_each_record(cells, b, z0 + l, z0 + l + 1, gather);
+      else for_each_record(cells, b, zl, zl + 1, gather);
     }
   }
   DPC_STAMP(11);

@@ -11,6 +11,7 @@
 #   pmc:<config>                     tools/profile_pmc.sh (SQ counters)
 #   ab:<bench args>:<variant>,<variant>,...   alternate library variants (main = in-tree, else scratch/<name>/), two rounds
 #   py:<script> [args]               python <script> under tools/ or scratch/, output -> <script>.log
+#   lib:<variant>                    later steps load scratch/<variant>/libdpc_render.so (tools/build_variant.sh); lib:main = in-tree
 # A step that fails stops the session (steps are joined with &&: nothing runs on a GPU a failed step may have left bad).
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -64,6 +65,9 @@ for step in "$@"; do
     py)
       script=${rest%% *}; timeout -k 10 900 python $rest > $OUT/$(basename $script).log 2>&1; rc=$?; tail -15 $OUT/$(basename $script).log
       [ $rc -ne 0 ] && { echo "py exit=$rc"; exit $rc; } ;;
+    lib)   # lib:<variant>  -- every later step of the session loads scratch/<variant>/libdpc_render.so (lib:main = the in-tree one)
+      if [ "$rest" = main ]; then unset DPC_RENDER_LIB; else export DPC_RENDER_LIB="$PWD/scratch/$rest/libdpc_render.so"; fi
+      echo "library: ${DPC_RENDER_LIB:-in-tree}" ;;
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
