@@ -724,6 +724,14 @@ constexpr int kFwdZs64 = DPC_FWD_ZS64;
 #ifndef DPC_BWD_ZS64
 #define DPC_BWD_ZS64 8
 #endif
+#ifndef DPC_BWD_ZS64_WIDE
+#define DPC_BWD_ZS64_WIDE 3
+#endif
+// The same at tap radius 5..10, where a row carries 12 pad floats and 7 + 1 planes would fill the LDS: that is 10 slabs per
+// cloud = 320 workgroups for 32 clouds, TWO rounds on 256 CUs (k_gather_hw<64,7,10> 32 us at sigma_rel 3.0, twice the
+// radius-3 kernel).  3 + 1 planes (78 KB, 512 threads) put two workgroups on a CU, whose load and gather phases overlap:
+// 27 us (4: 31.2, 5: 30.6; same box, alternating builds, profiles/r04_ab/).  At radius <= 4 the thin slabs lose (round 2).
+constexpr int kBwdZs64Wide = DPC_BWD_ZS64_WIDE;
 constexpr int kBwdZs64 = DPC_BWD_ZS64;  // cell layers per backward slab at G = 64 (8 -> 9 planes, 1 workgroup/CU; 3 -> 4 planes, 2/CU)  // planes per forward slab at G = 64 (4 -> 1 workgroup/CU, 2 -> 2 workgroups/CU)
 
 

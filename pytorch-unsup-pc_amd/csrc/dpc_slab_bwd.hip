@@ -380,7 +380,7 @@ int launch_gather_rb(const DpcParams* p, Cells cells, const float* pc, const flo
       if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
       if (p->H == 64) return launch_gather_fast<64, kBwdZs64, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
     } else if constexpr (RB <= 10) {
-      if (p->H == 64) return launch_gather_fast<64, 7, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
+      if (p->H == 64) return launch_gather_fast<64, kBwdZs64Wide, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
       if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);  // c4: sigma_rel 1.28 -> radius 8
       if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
     }
