@@ -9,8 +9,10 @@ One "step" = one pass of the hot path over one batch of synthetic clouds already
 pointcloud_project_fast (transform -> splat -> clamp -> Gaussian -> scale/clamp -> DRC silhouette), the loss
 sum((proj-gt)^2)/B, and the hand-written backward to d(pc), d(q), d(s).  Workload = BASELINE.json configs[1]
 (SURVEY.md 8(d) "c2"): B=32 clouds, N=8000 points, 64^3 grid, 21-tap Gaussian, sigma = 0.01 world units
-(sigma_rel 0.64).  The step is captured once into a HIP graph and replayed; weak scaling (every rank runs
-its own B=32 shard, no data-path collective; the per-step losses are all-reduced once after the timed loop).
+(sigma_rel 0.64).  By default a step is ONE native call (dpc_project_loss_step through dpc.render.project_loss_step) that
+enqueues the four kernels on static buffers -- no HIP graph; `--launch graph` captures the autograd path once and replays it
+(rounds 1-2).  Weak scaling: every rank runs its own B=32 shard, no data-path collective; the per-step losses are all-reduced
+once after the timed loop.
 
 `--gpus N` without a launcher starts the N ranks itself (a child `python -m torch.distributed.run ... bench.py` started
 before anything in this process touches a GPU) and relays rank 0's line; under torchrun (WORLD_SIZE set) it is a rank.
@@ -21,8 +23,9 @@ Prints ONE JSON line on rank 0.  `roofline` describes the dominant kernel (per-k
 the library's opt-in profiler, eager pass after the timed region, minus one event marker's cost);
 `roofline_step` prices the whole step with
 the contractual algorithmic bytes A(N,G) of SURVEY.md 8(d); `cpu_baseline` (the only part of this file that touches
-oracle/) times the CPU oracle (a port of the
-reference's PyTorch CPU path) on a bounded sample on this host.
+oracle/) times the CPU oracle (a port of the reference's PyTorch CPU path) on a bounded sample on this host.  Beside `value`,
+never as it: `step_us` (median of short windows), `hip_graph_replay`, `two_batches_in_flight`, `forward_only_us`, and the
+reference's own call sequence through the drop-in signatures, eager (`plain_eager`) and replayed (`plain_graph_replay`).
 """
 import argparse
 import json
@@ -87,7 +90,7 @@ def step_bytes_per_cloud(n, g, k_cand):
     return fwd + bwd / k_cand
 
 
-PROFILE_SUMMARIES = ("r03_rocprof_summary.json", "r03_rocprof_summary_c4.json", "r02_rocprof_summary.json",
+PROFILE_SUMMARIES = ("r04_rocprof_summary.json", "r04_rocprof_summary_c4.json", "r03_rocprof_summary.json", "r03_rocprof_summary_c4.json", "r02_rocprof_summary.json",
                      "r02_rocprof_summary_c4.json", "r01_rocprof_summary.json")   # newest first
 
 

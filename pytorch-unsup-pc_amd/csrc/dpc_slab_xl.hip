@@ -216,7 +216,13 @@ __global__ __launch_bounds__(ZS * kXWavesPerPlane * 64) void k_splat_xl(DpcParam
           for (int tp = 0; tp < 2 * RB + 1; ++tp) h = fmaf(taps.w[tp], v[j + e + tp], h);
           o[e] = wpass_lanes<RB>(h, taps);
         }
-        // one grid row per store instruction (lane = x: 256 contiguous bytes), written through (dpc_kernels.h)
+        // one grid row per store instruction (lane = x: 256 contiguous bytes), written through (dpc_kernels.h).
+        // (Round 3's other shape -- a 4 x 4 quad transpose over DPP quad permutes and ONE 16-byte buffer_store ... sc1 per lane --
+        // gave wrong values in lanes 13 + 16 k at tap radius 1.  Round 4 isolated that shape
+        // (tools/microbench/sc1_b128_store_probe.hip): value-identical to the ordinary store on the hardware at radius 1 and 3,
+        // and the old kernel rebuilt with it keeps every gfx9 hazard distance (VALU -> DPP two wait states, > 64-bit store data
+        // -> VALU write one).  Not a property of the instruction sequence; the failing build is not in the history.  The row
+        // stores are as fast and need no transpose -- profiles/LAB_NOTES.md A.6.)
 #ifdef DPC_ABLATE
         if (!DPC_ABL(5) || o[0] == 123.456f)
 #endif
