@@ -463,6 +463,49 @@ def test_long_kernel_falls_back_to_staged(R, O):
     close(out["proj"], ref["proj"], TOL)
 
 
+def test_grids_wider_than_the_lds_tile_are_refused_loudly(R, O):
+    """The slab kernels keep whole H x W planes in LDS (160 KiB per CU).  The differentiable path needs two of them (a cell
+    layer and its halo) for its backward, i.e. planes up to 141 x 141 besides the 128-wide kernels; beyond that EVERY entry
+    point of the path says so up front (DPC_ERR_LDS, 'an H x W plane does not fit the 160 KiB LDS tile') -- no fault, no
+    garbage, and no forward that succeeds only for its backward to raise.  The forward-only splat (pointcloud2voxels3d_fast)
+    needs one plane (up to 199 x 199).  (The reference takes any vox_size; its experiments use 32, 64 and 128.)  The widest
+    grids that are served are checked against the oracle."""
+    from dpc.render import _native
+    pc, q, s, _, _, _ = O.synth_inputs(2, 500, 16, 77)
+    for G, splat_ok in ((256, False), (192, True), (144, True)):
+        cfg = O.Cfg(vox_size=G, vox_size_z=8, pc_gauss_kernel_size=11)
+        kern = R.smoothing_kernel(cfg, 1.0)
+        gtG = torch.zeros(2, G, G, 1, device="cuda")
+        for call in (lambda: R.pointcloud_project_fast(cfg, dev(pc), dev(q), None, None, kern, scaling_factor=dev(s)),
+                     lambda: R.pointcloud_project_loss(cfg, dev(pc, True), dev(q, True), None, None, kern, scaling_factor=dev(s, True), gt=gtG)):
+            with pytest.raises(_native.DpcError) as err:
+                call()
+            assert err.value.code == _native.DPC_ERR_LDS and "LDS" in str(err.value)
+        if splat_ok:
+            vox, _ = R.pointcloud2voxels3d_fast(cfg, dev(pc, dtype=torch.float64), None)
+            ref, _ = O.pointcloud2voxels3d_fast(cfg, pc.double(), None)
+            close(vox, ref, TOL, "%d-wide forward-only splat" % G)
+        else:
+            with pytest.raises(_native.DpcError) as err:
+                R.pointcloud2voxels3d_fast(cfg, dev(pc, dtype=torch.float64), None)
+            assert err.value.code == _native.DPC_ERR_LDS
+    torch.cuda.synchronize()
+    # the widest grid of the differentiable path's generic kernels: 136 x 136 planes, forward and backward against the oracle
+    G = 136
+    cfg = O.Cfg(vox_size=G, vox_size_z=8, pc_gauss_kernel_size=11)
+    pc, q, s, gt, _, _ = O.synth_inputs(1, 3000, G, 78)
+    gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+    out = R.pointcloud_project_fast(cfg, gp, gq, None, None, R.smoothing_kernel(cfg, 1.0), scaling_factor=gs)
+    (((out["proj"] - dev(gt)) ** 2).sum()).backward()
+    cp, cq, cs = (x.clone().requires_grad_(True) for x in (pc, q, s))
+    ref = O.pointcloud_project_fast(cfg, cp, cq, None, None, O.smoothing_kernel(cfg, 1.0), scaling_factor=cs)
+    (((ref["proj"] - gt) ** 2).sum()).backward()
+    close(out["proj"], ref["proj"], TOL, "136-wide planes: proj")
+    close(gp.grad, cp.grad, TOL, "136-wide planes: dpc")
+    close(gq.grad, cq.grad, TOL, "136-wide planes: dq")
+    close(gs.grad, cs.grad, TOL, "136-wide planes: ds")
+
+
 def test_dead_branches_raise(R, O):
     pc, q = torch.zeros(1, 4, 3, device="cuda"), torch.ones(1, 4, device="cuda")
     with pytest.raises(NotImplementedError, match="all_rgb"):
