@@ -631,32 +631,36 @@ def main():
                 # smoothing_kernel, pointcloud_project_fast, the loss as torch ops, backward -- launched EAGERLY, no graph:
                 # what a caller that changes nothing but the import gets; host-bound, so this is a figure about the Python
                 # layer (round 3: 63 k clouds/s on the same box type), and the same sequence captured and replayed
-                def plain_step():
-                    k2 = R.smoothing_kernel(cfg, SIGMA_REL)
-                    pc.grad = q.grad = s.grad = None
-                    proj = R.pointcloud_project_fast(cfg, pc, q, None, None, k2, scaling_factor=s)["proj"]
-                    l = ((proj - gt) ** 2).sum() / B
-                    l.backward()
-                    return l
-                for _ in range(20):
-                    plain_step()
-                torch.cuda.synchronize(device)
-                n3 = 200
-                t3 = time.perf_counter()
-                for _ in range(n3):
-                    plain_step()
-                torch.cuda.synchronize(device)
-                t3 = time.perf_counter() - t3
-                extras["plain_eager"] = {"point_clouds_per_sec": B * n3 / t3, "us_per_step": 1e6 * t3 / n3,
-                                         "note": "pointcloud_project_fast + torch loss + backward, eager launches (host-bound); "
-                                                 "not the value of this line"}
-                pgraph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(pgraph, stream=side, capture_error_mode="thread_local"):
-                    plain_step()
-                pw = sorted(window_us(pgraph.replay, 20) for _ in range(15))
-                extras["plain_graph_replay"] = {"median_us": pw[len(pw) // 2], "best_us": pw[0],
-                                                "point_clouds_per_sec": B / (pw[len(pw) // 2] * 1e-6),
-                                                "note": "the same call sequence captured once and replayed; not the value of this line"}
+                try:
+                    def plain_step():
+                        k2 = R.smoothing_kernel(cfg, SIGMA_REL)
+                        pc.grad = q.grad = s.grad = None
+                        proj = R.pointcloud_project_fast(cfg, pc, q, None, None, k2, scaling_factor=s)["proj"]
+                        l = ((proj - gt) ** 2).sum() / B
+                        l.backward()
+                        return l
+                    for _ in range(20):
+                        plain_step()
+                    torch.cuda.synchronize(device)
+                    n3 = 200
+                    t3 = time.perf_counter()
+                    for _ in range(n3):
+                        plain_step()
+                    torch.cuda.synchronize(device)
+                    t3 = time.perf_counter() - t3
+                    extras["plain_eager"] = {"point_clouds_per_sec": B * n3 / t3, "us_per_step": 1e6 * t3 / n3,
+                                             "note": "pointcloud_project_fast + torch loss + backward, eager launches (host-bound); "
+                                                     "not the value of this line"}
+                    pgraph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(pgraph, stream=side, capture_error_mode="thread_local"):
+                        plain_step()
+                    pw = sorted(window_us(pgraph.replay, 20) for _ in range(15))
+                    extras["plain_graph_replay"] = {"median_us": pw[len(pw) // 2], "best_us": pw[0],
+                                                    "point_clouds_per_sec": B / (pw[len(pw) // 2] * 1e-6),
+                                                    "note": "the same call sequence captured once and replayed; not the value of this line"}
+
+                except Exception as exc:   # an extra beside the value must never cost the line itself
+                    extras["plain_eager"] = {"error": repr(exc)[:200]}
 
             def fwd_only():
                 with torch.no_grad():

@@ -71,3 +71,4 @@ for step in "$@"; do
     *) echo "unknown step $step"; exit 2 ;;
   esac
 done
+exit 0
