@@ -70,7 +70,8 @@ def _geometry(cfg, kernel=None, schedule=None):
     D, H, W = _grid(cfg)
     key = (D, H, W, _get(cfg, "camera_distance", 2.0), _get(cfg, "focal_length", 1.875), _get(cfg, "drc_logsum_clip_val", 1e-5),
            _get(cfg, "max_depth", 10.0), id(schedule))
-    cache = kernel.geometries if isinstance(kernel, KernelList) else (_plain_geometries if kernel is None else None)
+    cache = (kernel.geometries if isinstance(kernel, KernelList) and kernel.untouched()
+             else (_plain_geometries if kernel is None else None))
     if cache is not None:
         hit = cache.get(key)
         if hit is not None and hit.schedule is schedule:
@@ -137,7 +138,7 @@ def _kernel_taps(cfg, kernel):
     if not _get(cfg, "pc_separable_gauss_filter", True):
         raise NotImplementedError("pc_separable_gauss_filter: false leaves `kernel` unbound in the reference "
                                   "(dpc/util/gauss_kernel.py:52-55)")
-    if isinstance(kernel, KernelList):      # what smoothing_kernel returned: its host taps travel with it
+    if isinstance(kernel, KernelList) and kernel.untouched():   # what smoothing_kernel returned: its host taps travel with it
         return kernel.taps
     host = lambda k: np.ascontiguousarray(k.detach().cpu().numpy() if isinstance(k, torch.Tensor) else k,
                                           dtype=np.float32).reshape(-1)
@@ -169,13 +170,18 @@ class KernelList(list):
     derives from it on every call: the host tap arrays (`taps`) and the per-grid Geometry objects built from them
     (`geometries`), so that a step pays for them once per kernel instead of once per call."""
 
-    __slots__ = ("taps", "geometries")
+    __slots__ = ("taps", "geometries", "_made_of")
 
     def __init__(self, items):
         super().__init__(items)
         kx, kz = (np.ascontiguousarray(t.detach().cpu().numpy(), dtype=np.float32).reshape(-1) for t in (items[0], items[2]))
         self.taps = (kx, kz)
         self.geometries = {}
+        self._made_of = tuple(id(t) for t in items)
+
+    def untouched(self):
+        """Still the three tensors it was built from (a caller that replaced an element gets the slow, re-reading path)."""
+        return len(self) == 3 and tuple(id(t) for t in self) == self._made_of
 
 
 def separable_kernels(kernel):

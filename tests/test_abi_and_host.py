@@ -258,3 +258,35 @@ def test_grid_sized_store_streams_are_written_through_in_the_isa():
     assert any("global_store_dwordx2" in l and "sc1" in l for l in hw), "k_splat_hw<128,1,8> stores T without sc1"
     loc = _kernel_body(_device_asm("dpc_slab_fwd.o"), "k_locateILi0E")
     assert not any("global_store" in l and "sc1" in l for l in loc), "k_locate's record stores are meant to be ordinary"
+
+
+def test_kernel_lists_carry_their_taps_and_geometry():
+    """smoothing_kernel returns a list (what the reference's caller passes straight on) that also carries its host taps and the
+    Geometry objects built from it; the result is memoised per (size, sigma); a list whose elements a caller replaced is
+    re-read instead of trusted."""
+    import dpc.render as R
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+
+    cfg = Cfg(vox_size=32, vox_size_z=-1, pc_gauss_kernel_size=11)
+    k = R.smoothing_kernel(cfg, 1.5)
+    assert isinstance(k, list) and len(k) == 3 and [tuple(t.shape) for t in k] == [(1, 1, 1, 1, 11), (1, 1, 1, 11, 1), (1, 1, 11, 1, 1)]
+    assert R.smoothing_kernel(cfg, 1.5) is k and R.smoothing_kernel(cfg, 1.25) is not k
+    assert np.array_equal(k.taps[0], k[0].reshape(-1).numpy()) and np.array_equal(k.taps[1], k[2].reshape(-1).numpy())
+    g1, g2 = R._geometry(cfg, k), R._geometry(cfg, k)
+    assert g1 is g2 and np.array_equal(g1.kxy, k.taps[0]) and (g1.D, g1.H, g1.W) == (32, 32, 32)
+    cfg64 = Cfg(cfg, vox_size=64)
+    assert R._geometry(cfg64, k) is not g1 and R._geometry(cfg64, k).W == 64
+    # a caller that swaps an element: the list is read again, not trusted
+    k2 = R.smoothing_kernel(cfg, 0.75)
+    mine = type(k2)(list(k2))
+    mine[2] = k[2]
+    g3 = R._geometry(cfg, mine)
+    assert np.array_equal(g3.kz, k.taps[1]) and np.array_equal(g3.kxy, k2.taps[0]) and not mine.untouched()
+    # plain lists of tensors and bare 1-D kernels keep working
+    g4 = R._geometry(cfg, [t.clone() for t in k])
+    assert np.array_equal(g4.kxy, g1.kxy) and np.array_equal(g4.kz, g1.kz)
+    # DpcParams blocks and buffer sizes are cached per call shape (needs the library, not a GPU)
+    z1, z2 = g1.sized(4, 1000), g1.sized(4, 1000)
+    assert z1 is z2 and z1.cells_bytes > 0 and z1.ws_bytes >= 4 * 32 ** 3 * 4 and g1.sized(5, 1000) is not z1
