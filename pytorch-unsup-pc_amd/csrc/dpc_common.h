@@ -337,9 +337,11 @@ __device__ inline float window_dot(const float (&v)[L + 2 * RB], const TapsT<RB>
   return acc;
 }
 
-// Zero fill as a kernel.  The library never uses hipMemsetAsync: inside a captured and replayed HIP graph its memset nodes
-// did not reliably re-zero their buffer on this ROCm build (found in round 3: a captured training step drifted 7 % from
-// the eager one in 50 steps).
+// Zero fill as a kernel.  The library never uses hipMemsetAsync: with memset nodes for the fixed-point accumulators the captured
+// 300-kernel training step drifted 7 % from the eager one within 50 replays (round 3), and with this kernel it does not.  A graph
+// of nothing but memset -> kernel -> copy re-zeroes correctly on every replay (round 4, tools/microbench/memset_node_probe.py,
+// 4 KB .. 32 MB, through torch and through hipMemsetAsync on the capturing stream), so what went wrong inside the big graph
+// was never isolated; the kernel costs nothing and stays.
 static __global__ __launch_bounds__(256) void k_zero_words(unsigned int* __restrict__ p, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
 }
