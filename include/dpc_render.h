@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define DPC_ABI_VERSION 12
+#define DPC_ABI_VERSION 13
 #define DPC_MAX_TAPS 63 /* longest 1-D smoothing kernel accepted (pc_gauss_kernel_size) */
 
 enum {
@@ -122,6 +122,12 @@ int dpc_locate(const DpcParams* p, const float* pc, const float* q, const float*
                void* cells, void* stream);
 /* Scratch the fused BACKWARD entry points need (one grid-sized fp32 buffer + per-tile partial sums). */
 size_t dpc_workspace_bytes(const DpcParams* p);
+/* ABI 13.  DPC_OK when the grid of `p` can be served, DPC_ERR_LDS when not: the slab kernels keep whole H x W planes in LDS --
+ * one for the forward (planes up to 199 x 199), a cell layer plus its halo for the backward (up to 141 x 141; square 32 / 64 /
+ * 128 grids have kernels of their own).  The forward entry points succeed wherever the forward can run; a caller that knows a
+ * backward will follow asks with with_backward = 1 and refuses up front (the Python layer does, when gradients are required).
+ * The reference takes any vox_size (dpc/util/point_cloud_to.py:11-15); its experiments use 32, 64 and 128. */
+int dpc_check_grid(const DpcParams* p, int with_backward);
 
 /* ---------------------------------------------------------------------------------------------------
  * Fused hot path: replaces pointcloud_project_fast (dpc/util/point_cloud_to.py:191-263) =

@@ -27,6 +27,16 @@ size_t dpc_cells_bytes(const DpcParams* p) {
   return (size_t)p->B * num_chunks(p->N) * chunk_bytes(p->D);
 }
 
+// Can the grid of `p` be served: forward (one H x W plane in LDS), or forward AND backward (a cell layer plus its halo: two
+// planes)?  Square 32 / 64 / 128 grids have kernels of their own.  Lets a caller that knows a backward will follow refuse the
+// call up front instead of finding out in the backward.
+int dpc_check_grid(const DpcParams* p, int with_backward) {
+  const int rc = validate(p);
+  if (rc != DPC_OK) return rc;
+  if (p->H == p->W && (p->H == 32 || p->H == 64 || p->H == 128)) return DPC_OK;
+  return planes_fit(p) < (with_backward ? 2 : 1) ? DPC_ERR_LDS : DPC_OK;
+}
+
 size_t dpc_workspace_bytes(const DpcParams* p) {
   if (validate(p) != DPC_OK) return 0;
   return ws_total_bytes(p);   // layout: workspace_view() in dpc_kernels.h
@@ -78,10 +88,6 @@ int project_fwd_impl(const DpcParams* p, const float* pc, const float* q, const 
   if ((p->taps_xy > 0 && !host_kern_xy) || (p->taps_z > 0 && !host_kern_z)) return DPC_ERR_NULL;
   const TapPlan pxy = plan_taps(host_kern_xy, p->taps_xy), pz = plan_taps(host_kern_z, p->taps_z);
   if (pxy.bucket < 0) return DPC_ERR_TAPS;  // in-LDS passes need a radius bucket; caller composes the stage ops
-  // The differentiable path is refused as a whole where its BACKWARD could not run (a cell layer plus its halo plane in LDS:
-  // two H x W planes; 128-wide grids have kernels of their own): a forward that succeeds and a backward that then raises
-  // would be the worse surprise.  The forward-only stage functions (dpc_splat_fwd) need one plane.
-  if (!(p->H == p->W && (p->H == 32 || p->H == 64 || p->H == 128)) && planes_fit(p) < 2) return DPC_ERR_LDS;
   float* Tbuf = grid_wh;
   if ((rc = launch_locate(p, 0, pc, q, t, f, tr_pc, cells, st)) != DPC_OK) return rc;
   const Cells cv = cells_view(p, cells);

@@ -469,7 +469,7 @@ def pointcloud_project_fast(cfg, point_cloud, transform, predicted_translation, 
                                      scaling_factor, smooth, point_index)
     try:
         proj, grid_wh = ProjectFused.apply(point_cloud, transform, predicted_translation, focal_length, scaling_factor, geom,
-                                           point_index)
+                                           point_index, torch.is_grad_enabled())
     except _native.DpcError as e:
         if e.code != _native.DPC_ERR_TAPS:
             raise

@@ -14,7 +14,7 @@ _CSRC = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__))
 # other implementation to fall back to either way
 LIB_PATH = os.environ.get("DPC_RENDER_LIB") or os.path.join(_CSRC, "libdpc_render.so")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 DPC_MAX_TAPS = 63
 DPC_SMALL_COLS = 12
 COL_DQ, COL_DS, COL_DT, COL_DF = 0, 4, 5, 8
@@ -25,7 +25,7 @@ DPC_STATUS_BAD_INDEX = 1
 
 # every symbol include/dpc_render.h declares (tests/test_abi.py checks the header against this list)
 SYMBOLS = (
-    "dpc_abi_version", "dpc_strerror", "dpc_mask_words_per_plane", "dpc_cells_bytes", "dpc_workspace_bytes", "dpc_locate",
+    "dpc_abi_version", "dpc_strerror", "dpc_mask_words_per_plane", "dpc_cells_bytes", "dpc_workspace_bytes", "dpc_check_grid", "dpc_locate",
     "dpc_project_fwd", "dpc_project_bwd", "dpc_project_loss_fwd", "dpc_project_loss_bwd", "dpc_transform_fwd", "dpc_transform_bwd",
     "dpc_splat_fwd", "dpc_splat_bwd", "dpc_smooth", "dpc_drc_fwd", "dpc_drc_bwd",
     "dpc_silhouette_loss", "dpc_point_dropout_indices", "dpc_point_dropout_indices_live", "dpc_schedule_update", "dpc_taps_bucket",
@@ -72,6 +72,8 @@ def lib():
         L.dpc_cells_bytes.argtypes = [pp]
         L.dpc_workspace_bytes.restype = ctypes.c_size_t
         L.dpc_workspace_bytes.argtypes = [pp]
+        L.dpc_check_grid.restype = ctypes.c_int
+        L.dpc_check_grid.argtypes = [pp, ctypes.c_int]
         for name, nptr in (("dpc_project_fwd", 16), ("dpc_project_bwd", 17), ("dpc_transform_fwd", 6),
                            ("dpc_transform_bwd", 8), ("dpc_drc_fwd", 5), ("dpc_drc_bwd", 6), ("dpc_locate", 7)):
             fn = getattr(L, name)

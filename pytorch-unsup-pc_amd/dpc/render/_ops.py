@@ -71,7 +71,7 @@ class Geometry:
 class Sized:
     """A DpcParams block, a reference to it for the calls, and the sizes of the buffers a call with it needs."""
 
-    __slots__ = ("P", "ref", "wpp", "cells_bytes", "ws_bytes")
+    __slots__ = ("P", "ref", "wpp", "cells_bytes", "ws_bytes", "bwd_rc")
 
     def __init__(self, P):
         L = N.lib()
@@ -79,6 +79,13 @@ class Sized:
         self.wpp = L.dpc_mask_words_per_plane(self.ref)
         self.cells_bytes = max(L.dpc_cells_bytes(self.ref), 1)
         self.ws_bytes = max(L.dpc_workspace_bytes(self.ref), 1)
+        self.bwd_rc = L.dpc_check_grid(self.ref, 1)   # 0, or why a backward could not follow a forward of this shape
+
+    def require_backward(self, where):
+        """A call whose inputs require gradients is refused BEFORE anything is launched when its backward could not run (grids
+        wider than the backward's LDS tile): a forward that succeeds and a backward that then raises is the worse surprise."""
+        if self.bwd_rc != 0:
+            raise N.DpcError(self.bwd_rc, where + " (the inputs require gradients and the backward of this grid could not run)")
 
 
 _status = {}
@@ -310,7 +317,7 @@ class ProjectFused(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, pc, q, t, f, s, geom, point_index=None):
+    def forward(ctx, pc, q, t, f, s, geom, point_index=None, want_grad=False):
         dev = N.require_device(pc, q, t, f, s)
         L = N.lib()
         pc32, q32, t32, f32, s32 = _f32(pc), _f32(q), _f32(t), _f32(f), _f32(s)
@@ -318,6 +325,9 @@ class ProjectFused(torch.autograd.Function):
         B, reps = q32.shape[0], _replicas(pc32, q32)
         Npts = pc32.shape[1] if idx is None else idx.shape[1]
         Z = geom.sized(B, Npts, reps, idx, pc32.shape[1])
+        # grad mode is always off INSIDE forward(): the caller passes what it saw outside
+        if want_grad and B > 0 and any(x is not None and x.requires_grad for x in (pc, q, t, f, s)):
+            Z.require_backward("dpc_project_fwd")
         grid_wh = torch.empty((B, geom.D, geom.H, geom.W), dtype=torch.float32, device=dev)
         mask = torch.empty((B, geom.D, Z.wpp), dtype=torch.int64, device=dev)
         cells = torch.empty((Z.cells_bytes,), dtype=torch.uint8, device=dev)
@@ -342,7 +352,7 @@ class ProjectFused(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dproj, dgrid):
         if dproj is None and dgrid is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         pc32, q32, t32, f32, s32, grid_wh, mask, cells, trans = ctx.saved_tensors
         has_t, has_f, has_s = ctx.has
         t32 = t32 if has_t else None
@@ -370,7 +380,7 @@ class ProjectFused(torch.autograd.Function):
         return (_like_input(dpc, pc), _like_input(_small(dsmall, N.COL_DQ, 4, B), q),
                 _like_input(_small(dsmall, N.COL_DT, 3, B), t) if has_t else None,
                 _like_input(_small(dsmall, N.COL_DF, 1, B), f) if has_f else None,
-                _like_input(_small(dsmall, N.COL_DS, 1, B), s) if has_s else None, None, None)
+                _like_input(_small(dsmall, N.COL_DS, 1, B), s) if has_s else None, None, None, None)
 
 
 class ProjectLossFused(torch.autograd.Function):
@@ -418,6 +428,8 @@ class ProjectLossFused(torch.autograd.Function):
         # backward buffers handed to the forward so it can run the column half of the backward right away -- only when a
         # backward can follow (grad mode is always off INSIDE forward(): the caller passes what it saw outside)
         want_grad = want_grad and any(x is not None and x.requires_grad for x in (pc, q, t, f, s))
+        if want_grad:
+            Z.require_backward("dpc_project_loss_fwd")
         ws = dsmall = None
         if want_grad and K == 1:
             ws = torch.empty((Z.ws_bytes,), dtype=torch.uint8, device=dev)

@@ -464,31 +464,40 @@ def test_long_kernel_falls_back_to_staged(R, O):
 
 
 def test_grids_wider_than_the_lds_tile_are_refused_loudly(R, O):
-    """The slab kernels keep whole H x W planes in LDS (160 KiB per CU).  The differentiable path needs two of them (a cell
-    layer and its halo) for its backward, i.e. planes up to 141 x 141 besides the 128-wide kernels; beyond that EVERY entry
-    point of the path says so up front (DPC_ERR_LDS, 'an H x W plane does not fit the 160 KiB LDS tile') -- no fault, no
-    garbage, and no forward that succeeds only for its backward to raise.  The forward-only splat (pointcloud2voxels3d_fast)
-    needs one plane (up to 199 x 199).  (The reference takes any vox_size; its experiments use 32, 64 and 128.)  The widest
-    grids that are served are checked against the oracle."""
+    """The slab kernels keep whole H x W planes in LDS (160 KiB per CU): one for the forward (planes up to 199 x 199), a cell
+    layer plus its halo for the backward (up to 141 x 141 besides the 32 / 64 / 128-wide kernels).  Beyond the forward's limit
+    every entry point raises DPC_ERR_LDS ('an H x W plane does not fit the 160 KiB LDS tile'); between the two limits a
+    forward-only call (no_grad, or inputs without gradients: prediction, evaluation) is served and checked against the oracle,
+    while a call whose inputs require gradients is refused UP FRONT (dpc_check_grid) rather than in its backward -- no fault,
+    no garbage, at any size.  (The reference takes any vox_size; its experiments use 32, 64 and 128.)"""
     from dpc.render import _native
     pc, q, s, _, _, _ = O.synth_inputs(2, 500, 16, 77)
-    for G, splat_ok in ((256, False), (192, True), (144, True)):
+    for G in (256, 192, 144):
         cfg = O.Cfg(vox_size=G, vox_size_z=8, pc_gauss_kernel_size=11)
         kern = R.smoothing_kernel(cfg, 1.0)
-        gtG = torch.zeros(2, G, G, 1, device="cuda")
-        for call in (lambda: R.pointcloud_project_fast(cfg, dev(pc), dev(q), None, None, kern, scaling_factor=dev(s)),
-                     lambda: R.pointcloud_project_loss(cfg, dev(pc, True), dev(q, True), None, None, kern, scaling_factor=dev(s, True), gt=gtG)):
+        gtG = O.synth_inputs(2, 1, G, 79)[3]
+        with_grad = (lambda: R.pointcloud_project_fast(cfg, dev(pc, True), dev(q), None, None, kern, scaling_factor=dev(s)),
+                     lambda: R.pointcloud_project_loss(cfg, dev(pc), dev(q, True), None, None, kern, scaling_factor=dev(s, True), gt=dev(gtG)))
+        for call in with_grad:
             with pytest.raises(_native.DpcError) as err:
                 call()
             assert err.value.code == _native.DPC_ERR_LDS and "LDS" in str(err.value)
-        if splat_ok:
-            vox, _ = R.pointcloud2voxels3d_fast(cfg, dev(pc, dtype=torch.float64), None)
-            ref, _ = O.pointcloud2voxels3d_fast(cfg, pc.double(), None)
-            close(vox, ref, TOL, "%d-wide forward-only splat" % G)
+        forward_only = (lambda: R.pointcloud_project_fast(cfg, dev(pc), dev(q), None, None, kern, scaling_factor=dev(s))["proj"],
+                        lambda: R.pointcloud_project_loss(cfg, dev(pc), dev(q), None, None, kern, scaling_factor=dev(s), gt=dev(gtG))[1]["proj"],
+                        lambda: R.pointcloud2voxels3d_fast(cfg, dev(pc, dtype=torch.float64), None)[0])
+        if G > 199:
+            for call in forward_only:
+                with pytest.raises(_native.DpcError) as err:
+                    call()
+                assert err.value.code == _native.DPC_ERR_LDS
         else:
-            with pytest.raises(_native.DpcError) as err:
-                R.pointcloud2voxels3d_fast(cfg, dev(pc, dtype=torch.float64), None)
-            assert err.value.code == _native.DPC_ERR_LDS
+            ref = O.pointcloud_project_fast(cfg, pc, q, None, None, O.smoothing_kernel(cfg, 1.0), scaling_factor=s)
+            with torch.no_grad():
+                hard = R.pointcloud_project_fast(cfg, dev(pc, True), dev(q, True), None, None, kern, scaling_factor=dev(s, True))["proj"]
+            close(hard, ref["proj"], TOL, "%d-wide forward under no_grad: proj" % G)
+            close(forward_only[0](), ref["proj"], TOL, "%d-wide forward-only call: proj" % G)
+            close(forward_only[1](), ref["proj"], TOL, "%d-wide forward-only loss call: proj" % G)
+            close(forward_only[2](), O.pointcloud2voxels3d_fast(cfg, pc.double(), None)[0], TOL, "%d-wide forward-only splat" % G)
     torch.cuda.synchronize()
     # the widest grid of the differentiable path's generic kernels: 136 x 136 planes, forward and backward against the oracle
     G = 136
