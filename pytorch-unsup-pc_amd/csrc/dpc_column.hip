@@ -270,8 +270,8 @@ void k_zcol_fwdbwd(DpcParams P, RayHost rh, const float* __restrict__ Tbuf, cons
         for (int r = 0; r < RPL; ++r) {
           float a = 0.f;
 #pragma unroll
-          for (int k = 0; k < 2 * RB + 1; ++k) {
-            const int zz = zo + k - RB;
+          for (int i = 0; i < 2 * RB + 1; ++i) {
+            const int k = tap_edge_first<RB>(i), zz = zo + k - RB;   // adjoint D pass: edges first, centre last (dpc_common.h)
             if (zz >= 0 && zz < DD) a = fmaf(wadj[k], y[zz][r], a);
           }
           acc[r] = a;
@@ -477,8 +477,8 @@ __global__ __launch_bounds__(kColThreads, 2) void k_zcol_bwd(DpcParams P, RayHos
         const int zo = z - RB;
         float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 2 * RB + 1; ++k) {
-          const int zz = zo + k - RB;
+        for (int i = 0; i < 2 * RB + 1; ++i) {
+          const int k = tap_edge_first<RB>(i), zz = zo + k - RB;   // adjoint D pass: edges first, centre last (dpc_common.h)
           if (zz >= 0 && zz < DD) acc = fmaf(taps_adj.w[k], d[zz], acc);
         }
         if (extra != nullptr) acc += extra[(size_t)zo * HW];

@@ -518,8 +518,10 @@ __device__ inline void hpass_global(const float* __restrict__ src, int planes_pr
       for (int j = 0; j < Geo::LH; ++j) {
         f32x2 acc = f32x2{0.f, 0.f};
 #pragma unroll
-        for (int tp = 0; tp < 2 * RB + 1; ++tp)
+        for (int i = 0; i < 2 * RB + 1; ++i) {
+          const int tp = tap_edge_first<RB>(i);   // an adjoint pass: edges first, centre last (dpc_common.h)
           acc = __builtin_elementwise_fma(f32x2{taps.w[tp], taps.w[tp]}, v[j + tp], acc);
+        }
         store(z, seg * Geo::LH + j, 2 * xp, acc);
       }
     }

@@ -195,7 +195,10 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
         for (int e = 0; e < 2; ++e) {
           float acc = 0.f;
 #pragma unroll
-          for (int tp = 0; tp < 2 * RB + 1; ++tp) acc = fmaf(taps_adj.w[tp], v[e + tp], acc);
+          for (int i = 0; i < 2 * RB + 1; ++i) {
+            const int tp = tap_edge_first<RB>(i);   // edges first, centre last (dpc_common.h)
+            acc = fmaf(taps_adj.w[tp], v[e + tp], acc);
+          }
           const int x = c.ix + e;
           const bool pass = x < GS && ((mlds[row * (GS / 32) + (x >> 5)] >> (x & 31)) & 1u);
           o[e] = pass ? acc : 0.f;
