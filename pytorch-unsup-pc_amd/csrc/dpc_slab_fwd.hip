@@ -165,7 +165,8 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
     if (loss_zero != nullptr && bk.y == 0) *loss_zero = 0.f;
   }
   const int D = P.D, H = P.H, W = P.W;
-  const int Zs = GS ? ZS : zs_rt;
+  // generic kernel: |zs_rt| planes per slab; zs_rt < 0 = float accumulators (planes so wide that only ONE 4-byte plane fits)
+  const int Zs = GS ? ZS : (zs_rt < 0 ? -zs_rt : zs_rt);
   const int b = bk.y, z0 = bk.x * Zs;
   const int nz = min(Zs, D - z0);
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -338,7 +339,15 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
    }
   } else {
     const int WP = odd_stride(W);
-    for (int i = tid; i < nz * H * WP; i += nthr) slab[i] = 0.f;
+    const int nvox = nz * H * WP;
+    // Accumulators: 64-bit fixed point like the specialised kernels (exact, so the sums -- and everything downstream -- are the
+    // same bits whatever order the points arrive in), 8 bytes per voxel, turned into the fp32 slab in place afterwards.  Only
+    // planes so wide that a single 8-byte plane does not fit (zs_rt < 0: beyond ~141 x 141, forward-only territory) fall back
+    // to float LDS atomics, whose arrival order shows in the last bits.
+    const bool acc64 = zs_rt > 0;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(slab);
+    if (acc64) for (int i = tid; i < nvox; i += nthr) acc[i] = 0ull;
+    else for (int i = tid; i < nvox; i += nthr) slab[i] = 0.f;
     __syncthreads();
     for_each_record(cells, b, max(z0 - 1, 0), z0 + nz, [&](const PointRec& rec, const int4*) {
       const Cell c = cell_from_record(rec);
@@ -354,7 +363,9 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
           for (int e = 0; e < 2; ++e) {
             const int xx = c.ix + e;
             if (xx >= W) continue;
-            atomicAdd(&slab[(zz * H + yy) * WP + xx], c.wz[k] * c.wy[j] * c.wx[e]);  // ds_add_f32
+            const float wt = c.wz[k] * c.wy[j] * c.wx[e];
+            if (acc64) atomicAdd(&acc[(zz * H + yy) * WP + xx], to_fixed(wt));   // ds_add_u64
+            else atomicAdd(&slab[(zz * H + yy) * WP + xx], wt);                 // ds_add_f32
           }
         }
       }
@@ -369,11 +380,44 @@ __global__ __launch_bounds__(kSlabThreads) void k_splat_hw(DpcParams P, Cells ce
         const int idx = c * 64 + lane;
         const bool in = idx < iHW;
         const int y = idx / W, x = idx - y * W;
-        const float vraw = in ? slab[(z * H + y) * WP + x] : 2.f;
-        const unsigned long long bits = __ballot(in && vraw <= 1.0f);
+        float vraw = 2.f;
+        bool pass = false;
+        if (in) {
+          if (acc64) {
+            const unsigned long long a = acc[(z * H + y) * WP + x];
+            vraw = from_fixed(a);
+            pass = a <= kFixOne;           // decided on the exact integer, like the specialised kernels
+          } else {
+            vraw = slab[(z * H + y) * WP + x];
+            pass = vraw <= 1.0f;
+          }
+        }
+        const unsigned long long bits = __ballot(pass);
         if (mask != nullptr && lane == 0) mask[((size_t)b * D + z0 + z) * wpp + c] = bits;
         if (raw != nullptr && in) raw[((size_t)b * D + z0 + z) * iHW + idx] = vraw;
       }
+    }
+    if (acc64 && Tbuf != nullptr) {
+      // accumulators -> fp32 slab, in place: float i lands on the bytes of accumulator i / 2, so the slab is converted in
+      // chunks -- a chunk's accumulators are all read before any of its floats is written, and the floats of chunk c only
+      // reach into accumulators of chunks <= c
+      constexpr int CH = 8;
+      __syncthreads();   // the mask pass is done with the accumulators
+      for (int base = 0; base < nvox; base += CH * nthr) {
+        unsigned long long r[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const int i = base + k * nthr + tid;
+          r[k] = i < nvox ? acc[i] : 0ull;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const int i = base + k * nthr + tid;
+          if (i < nvox) slab[i] = from_fixed(r[k]);
+        }
+      }
+      __syncthreads();
     }
     if (Tbuf == nullptr) return;
     float* Tout = Tbuf + ((size_t)b * D + z0) * HW;
@@ -436,14 +480,17 @@ int launch_splat_rb(const DpcParams* p, Cells cells, const float* kxy, const Tap
   }
   const int fit = planes_fit(p);
   if (fit < 1) return DPC_ERR_LDS;
-  const int Zs = std::min(fit, std::max(1, (p->D + 7) / 8));
-  const size_t lds = (size_t)Zs * p->H * (p->W | 1) * sizeof(float);
+  // 64-bit fixed-point accumulators (8 bytes per voxel) wherever a plane of them fits; the kernel says which by the sign of
+  // its slab-thickness argument
+  const bool acc64 = fit >= 2;
+  const int Zs = std::min(acc64 ? fit / 2 : fit, std::max(1, (p->D + 7) / 8));
+  const size_t lds = (size_t)Zs * p->H * (p->W | 1) * (acc64 ? sizeof(unsigned long long) : sizeof(float));
   auto kern = k_splat_hw<0, 0, RB>;
   static LdsLimit limit;
   int rc = set_lds(kern, lds, limit);
   if (rc != DPC_OK) return rc;
   DPC_LAUNCH("k_splat_hw", kern, dim3(((p->D + Zs - 1) / Zs) * p->B), dim3(slab_threads(p)), lds, st, *p, cells,
-             make_taps<RB>(kxy, pxy, false), Zs, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
+             make_taps<RB>(kxy, pxy, false), acc64 ? Zs : -Zs, raw, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
   return launch_ok();
 }
 

@@ -463,6 +463,38 @@ def test_long_kernel_falls_back_to_staged(R, O):
     close(out["proj"], ref["proj"], TOL)
 
 
+@pytest.mark.parametrize("G,Gz", [(48, -1), (24, 40), (96, 12)])
+def test_generic_grid_widths_are_bit_reproducible_too(R, O, G, Gz):
+    """Grids without kernels of their own (any width but 32 / 64 / 128) take the generic slab kernels.  Their splat accumulates in
+    64-bit fixed point as well (it used float LDS atomics, whose arrival order showed in the last bits): five runs of the same
+    call give identical bits for the raw grid, the silhouettes and every gradient, and the values are the oracle's."""
+    B, N = 5, 4000
+    cfg = O.Cfg(vox_size=G, vox_size_z=Gz, pc_gauss_kernel_size=11)
+    kern = R.smoothing_kernel(cfg, 1.1)
+    pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 6100 + G)
+    pc = (pc * 0.35).contiguous()       # many points per voxel: long accumulation chains, where arrival order would show
+    runs = []
+    for _ in range(5):
+        gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+        out = R.pointcloud_project_fast(cfg, gp, gq, None, None, kern, scaling_factor=gs)
+        (((out["proj"] - dev(gt)) ** 2).sum() / B).backward()
+        raw, _ = R.pointcloud2voxels3d_fast(cfg, out["tr_pc"].detach(), None)
+        runs.append([x.detach().clone() for x in (raw, out["proj"], gp.grad, gq.grad, gs.grad)])
+    for r in runs[1:]:
+        for name, a, b_ in zip(("raw", "proj", "dpc", "dq", "ds"), r, runs[0]):
+            assert torch.equal(a, b_), "%s differs between two runs on a %d-wide grid" % (name, G)
+    cp, cq, cs = (x.clone().requires_grad_(True) for x in (pc, q, s))
+    ref = O.pointcloud_project_fast(cfg, cp, cq, None, None, O.smoothing_kernel(cfg, 1.1), scaling_factor=cs)
+    (((ref["proj"] - gt) ** 2).sum() / B).backward()
+    raw, proj, dpc, dq, ds = runs[0]
+    assert float(ref["voxels_raw"].max()) > 3.0, "the test wants voxels that collect many points"
+    close(raw, ref["voxels_raw"], TOL, "generic %d-wide grid: raw" % G)
+    close(proj, ref["proj"], TOL, "generic %d-wide grid: proj" % G)
+    close(dpc, cp.grad, TOL, "generic %d-wide grid: dpc" % G)
+    close(dq, cq.grad, TOL, "generic %d-wide grid: dq" % G)
+    close(ds, cs.grad, TOL, "generic %d-wide grid: ds" % G)
+
+
 def test_grids_wider_than_the_lds_tile_are_refused_loudly(R, O):
     """The slab kernels keep whole H x W planes in LDS (160 KiB per CU): one for the forward (planes up to 199 x 199), a cell
     layer plus its halo for the backward (up to 141 x 141 besides the 32 / 64 / 128-wide kernels).  Beyond the forward's limit
