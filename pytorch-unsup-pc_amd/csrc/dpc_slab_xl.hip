@@ -10,6 +10,8 @@
 // The forward needs no fp32 copy of the slab at all (accumulators -> registers -> global).  (A backward on the same plan --
 // d(raw) fully filtered in LDS, 8 reads per gathered point -- measured slower than k_gather_hw in round 2: its dT load phase
 // is 4-byte loads at one x per lane against 8-byte column pairs; it was removed in round 3, git history has it.)
+#include <type_traits>
+
 #include "dpc_kernels.h"
 
 DPC_DEBUG_SETTERS(xl)
@@ -46,6 +48,28 @@ __device__ inline float wpass_lanes(float v, const TapsT<RB>& taps) {
   return acc;
 }
 
+// The same for a SYMMETRIC kernel (every Gaussian is, bit for bit: exp(-x^2 / 2 sigma^2) of +-x), as a Horner scheme over the
+// lanes:  out = w_0 v + shr(P_1 + shr(P_2 + ... shr(P_RB))) + shl(P_1 + shl(P_2 + ... shl(P_RB))),  P_k = w_k v.
+// The products are shared by the two sides and every shifted value is used exactly once, so the shift rides on the add as its
+// DPP operand: 3 RB + 1 instructions per output instead of 4 RB + 1 (RB = 3: 10 against 13).
+template <int RB>
+__device__ inline float wpass_lanes_sym(float v, const TapsT<RB>& taps) {
+#pragma clang fp contract(off)   // the products stay products (shared by both sides); the adds take the shifts as DPP operands
+  float p[RB + 1];
+#pragma unroll
+  for (int k = 1; k <= RB; ++k) p[k] = taps.w[RB + k] * v;
+  float l = p[RB], r = p[RB];
+#pragma unroll
+  for (int k = RB - 1; k >= 1; --k) {
+    l = p[k] + from_lane_below(l);
+    r = p[k] + from_lane_above(r);
+  }
+  float acc = taps.w[RB] * v;
+  acc += from_lane_below(l);
+  acc += from_lane_above(r);
+  return acc;
+}
+
 // ------------------------------------------------------------------------------------------------------
 // Forward: splat into 64-bit fixed-point accumulators (as k_splat_hw), then per thread: a y window of accumulators at
 // one x -> clamp mask words by ballot -> H pass in registers -> W pass across lanes -> T.     grid (D/ZS) x B, ZS*256 threads
@@ -56,7 +80,7 @@ __global__ __launch_bounds__(ZS * kXWavesPerPlane * 64) void k_splat_xl(DpcParam
                                                        float* __restrict__ Tbuf,
                                                        uint64_t* __restrict__ mask, float* __restrict__ sse,
                                                        float* __restrict__ loss_zero, int* __restrict__ winner_zero,
-                                                       unsigned long long* __restrict__ ticket_zero) {
+                                                       unsigned long long* __restrict__ ticket_zero, int symmetric) {
   extern __shared__ __attribute__((aligned(16))) float slab[];
   constexpr int NT = ZS * kXWavesPerPlane * 64, PR = kXG + 2 * RB, ACC = ZS * PR * kXG, WIN = kXSeg + 2 * RB;
   static_assert(ACC % 4 == 0, "zero fill in 16-byte words, two halves");
@@ -203,34 +227,43 @@ __global__ __launch_bounds__(ZS * kXWavesPerPlane * 64) void k_splat_xl(DpcParam
       if (round == 0) DPC_STAMP(3);
       // four rows at a time: H pass in registers, W pass across the lanes, four row stores
       float* Tout = Tbuf + (((size_t)b * D + z0 + zz) * kXG + y0) * kXG + lane;
+      // `symmetric` (block-uniform; set by the launcher for a kernel that equals its mirror image bit for bit and whose values
+      // travel with the launch): the W pass takes the Horner form of wpass_lanes_sym, 10 instead of 13 instructions per output
+      // at radius 3 (k_splat_xl 15.0 -> 14.75 us at c2, 52.1 -> 49.3 us for the 128 clouds of c5)
+      auto rows = [&](auto sym_tag) {
+        constexpr bool kSym = decltype(sym_tag)::value;
 #pragma unroll
-      for (int j = 0; j < kXSeg; j += 4) {
-        float o[4];
+        for (int j = 0; j < kXSeg; j += 4) {
+          float o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float h = 0.f;
+          for (int e = 0; e < 4; ++e) {
+            float h = 0.f;
 #ifdef DPC_ABLATE
-          if (DPC_ABL(6)) { o[e] = v[j + e + RB]; continue; }
+            if (DPC_ABL(6)) { o[e] = v[j + e + RB]; continue; }
 #endif
 #pragma unroll
-          for (int tp = 0; tp < 2 * RB + 1; ++tp) h = fmaf(taps.w[tp], v[j + e + tp], h);
-          o[e] = wpass_lanes<RB>(h, taps);
-        }
-        // one grid row per store instruction (lane = x: 256 contiguous bytes), written through (dpc_kernels.h).
-        // (Round 3's other shape -- a 4 x 4 quad transpose over DPP quad permutes and ONE 16-byte buffer_store ... sc1 per lane --
-        // gave wrong values in lanes 13 + 16 k at tap radius 1.  Round 4 isolated that shape
-        // (tools/microbench/sc1_b128_store_probe.hip): value-identical to the ordinary store on the hardware at radius 1 and 3,
-        // and the old kernel rebuilt with it keeps every gfx9 hazard distance (VALU -> DPP two wait states, > 64-bit store data
-        // -> VALU write one).  Not a property of the instruction sequence; the failing build is not in the history.  The row
-        // stores are as fast and need no transpose -- profiles/LAB_NOTES.md A.6.)
+            for (int tp = 0; tp < 2 * RB + 1; ++tp) h = fmaf(taps.w[tp], v[j + e + tp], h);
+            if constexpr (kSym) o[e] = wpass_lanes_sym<RB>(h, taps);
+            else o[e] = wpass_lanes<RB>(h, taps);
+          }
+          // one grid row per store instruction (lane = x: 256 contiguous bytes), written through (dpc_kernels.h).
+          // (Round 3's other shape -- a 4 x 4 quad transpose over DPP quad permutes and ONE 16-byte buffer_store ... sc1 per lane
+          // -- gave wrong values in lanes 13 + 16 k at tap radius 1.  Round 4 isolated that shape
+          // (tools/microbench/sc1_b128_store_probe.hip): value-identical to the ordinary store on the hardware at radius 1 and 3,
+          // and the old kernel rebuilt with it keeps every gfx9 hazard distance (VALU -> DPP two wait states, > 64-bit store
+          // data -> VALU write one).  Not a property of the instruction sequence; the failing build is not in the history.  The
+          // row stores are as fast and need no transpose -- profiles/LAB_NOTES.md A.6.)
 #ifdef DPC_ABLATE
-        if (!DPC_ABL(5) || o[0] == 123.456f)
+          if (!DPC_ABL(5) || o[0] == 123.456f)
 #endif
-        {
+          {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) store_through(Tout + (size_t)(j + e) * kXG, o[e]);
+            for (int e = 0; e < 4; ++e) store_through(Tout + (size_t)(j + e) * kXG, o[e]);
+          }
         }
-      }
+      };
+      if (symmetric) rows(std::true_type{});
+      else rows(std::false_type{});
     }
     if (!more) break;
     request_records(rr_next);
@@ -258,8 +291,13 @@ int launch_splat_xl_zr(const DpcParams* p, Cells cells, const float* kxy, const 
   for (int c = 2; c <= 16; c *= 2)
     if (nslab % c == 0 && (size_t)(nslab / c) * p->B >= (size_t)kNumCUs * DPC_XL_WGS_PER_CU) nround = c;
 #endif
+  // the Horner W pass wants w[RB - k] == w[RB + k] bit for bit (every Gaussian: exp(-x^2 / 2 sigma^2) of +-x) and the values
+  // in the launch itself (tap values read from device memory under a DeviceSchedule are not inspected here)
+  const TapsT<RB> tw = make_taps<RB>(kxy, pxy, false);
+  int symmetric = p->dev_taps_xy == nullptr;
+  for (int k = 1; k <= RB; ++k) symmetric = symmetric && memcmp(&tw.w[RB - k], &tw.w[RB + k], sizeof(float)) == 0;
   DPC_LAUNCH("k_splat_xl", kern, dim3((nslab / nround) * p->B), dim3(ZS * kXWavesPerPlane * 64), lds, st, *p, cells,
-             make_taps<RB>(kxy, pxy, false), nround, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero);
+             tw, nround, Tbuf, mask, sse, loss_zero, winner_zero, ticket_zero, symmetric);
   return launch_ok();
 }
 

@@ -463,6 +463,37 @@ def test_long_kernel_falls_back_to_staged(R, O):
     close(out["proj"], ref["proj"], TOL)
 
 
+@pytest.mark.parametrize("G", [64, 32, 48])
+def test_asymmetric_smoothing_kernel(R, O, G):
+    """The API takes any separable 1-D kernel (the reference's smoothen_voxels3d is a plain conv3d with whatever it is given,
+    point_cloud_to.py:90-103), not only Gaussians: a skewed 7-tap kernel through the x-in-lanes forward kernel (64-wide: its
+    W pass has a shorter form for symmetric kernels, which the launcher must NOT pick here), the LDS-window kernels (32-wide)
+    and the generic ones (48-wide), forward and backward -- the backward correlates with the mirrored kernel -- against the
+    oracle."""
+    B, N = 3, 2500
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=7)
+    k1 = torch.tensor([0.02, 0.08, 0.25, 0.35, 0.18, 0.09, 0.03])
+    kernel = [k1.reshape(1, 1, 1, 1, 7), k1.reshape(1, 1, 1, 7, 1), k1.reshape(1, 1, 7, 1, 1)]
+    pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 6200 + G)
+    gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+    out = R.pointcloud_project_fast(cfg, gp, gq, None, None, kernel, scaling_factor=gs)
+    (((out["proj"] - dev(gt)) ** 2).sum() / B).backward()
+    cp, cq, cs = (x.clone().requires_grad_(True) for x in (pc, q, s))
+    ref = O.pointcloud_project_fast(cfg, cp, cq, None, None, kernel, scaling_factor=cs)
+    (((ref["proj"] - gt) ** 2).sum() / B).backward()
+    close(out["proj"], ref["proj"], TOL, "asymmetric kernel, %d-wide: proj" % G)
+    close(out["voxels"], ref["voxels"], TOL, "asymmetric kernel, %d-wide: voxels" % G)
+    close(gp.grad, cp.grad, TOL, "asymmetric kernel, %d-wide: dpc" % G)
+    close(gq.grad, cq.grad, TOL, "asymmetric kernel, %d-wide: dq" % G)
+    close(gs.grad, cs.grad, TOL, "asymmetric kernel, %d-wide: ds" % G)
+    # the fused loss and its one-call plan take the same kernel
+    hp, hq, hs = dev(pc, True), dev(q, True), dev(s, True)
+    loss, o2, _ = R.pointcloud_project_loss(cfg, hp, hq, None, None, kernel, scaling_factor=hs, gt=dev(gt))
+    loss.backward()
+    close(o2["proj"], ref["proj"], TOL, "asymmetric kernel, %d-wide, fused loss: proj" % G)
+    close(hp.grad, cp.grad, TOL, "asymmetric kernel, %d-wide, fused loss: dpc" % G)
+
+
 @pytest.mark.parametrize("G,Gz", [(48, -1), (24, 40), (96, 12)])
 def test_generic_grid_widths_are_bit_reproducible_too(R, O, G, Gz):
     """Grids without kernels of their own (any width but 32 / 64 / 128) take the generic slab kernels.  Their splat accumulates in
