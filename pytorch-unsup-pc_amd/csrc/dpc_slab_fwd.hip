@@ -18,13 +18,14 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
                                                         const float* __restrict__ q, const float* __restrict__ t,
                                                         const float* __restrict__ f, float* __restrict__ tr_pc,
                                                         uint8_t* __restrict__ cells_out) {
-  // Counting sort by bin that is STABLE without any ordered atomic: every thread sets its own bit in its bin's 256-bit
-  // membership mask (ds_or, result independent of arrival order); a bin's population is the popcount of its mask and a
-  // point's rank inside the bin the popcount below its own bit.  (Ranks handed out by an atomic counter are arrival order,
-  // which changes from run to run -- and the order of the records inside a bin decides which thread of the backward adds
-  // which point into its partial sums.)
-  __shared__ int hist[1026];                          // D + 2 <= 1026 bins (validate() caps D at 1024)
-  extern __shared__ __attribute__((aligned(16))) unsigned int member[];   // (D + 1) x 8 words, sized by the launch
+  // Counting sort by bin that is STABLE without any ordered atomic (ranks handed out by an atomic counter are arrival order,
+  // which changes from run to run -- and the order of the records inside a bin decides which thread of the backward adds which
+  // point into its partial sums).  [r4] By ballots instead of 256-bit membership masks in LDS: a wave finds, for every lane,
+  // the lanes that share its bin (one ballot per bit of the bin number), the rank inside the wave is the popcount below the
+  // lane (v_mbcnt), the first lane of every group leaves the group's size in cnt[wave][bin], and the first wave turns the
+  // 4 x (D + 1) counts into start positions -- no LDS atomics, a quarter of the LDS, the same order as before bit for bit.
+  extern __shared__ __attribute__((aligned(16))) int cnt[];   // [waves][D + 1] group sizes, then start positions; sized by the launch
+  __shared__ int total_pts;
   const Blk bk = block_coords(P.B);
   const int b = bk.y, blk = bk.x, tid = threadIdx.x;
   const int D = P.D, nbins = D + 1;
@@ -33,8 +34,8 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
   // it short: the points beyond it become out-of-bounds records (bin D) that no later kernel looks at
   const int n_live = P.n_live != nullptr ? min(P.N, *P.n_live) : P.N;
   const bool present = i < P.N, live = i < n_live;
-  constexpr int MW = kLocThreads / 32;  // mask words per bin
-  for (int k = tid; k < nbins * MW; k += kLocThreads) member[k] = 0u;
+  constexpr int NW = kLocThreads / DPC_WAVE;
+  for (int k = tid; k < nbins * NW; k += kLocThreads) cnt[k] = 0;
   PointRec rec;
   rec.code = -1; rec.tz = rec.ty = rec.tx = 0.f;
   float src_pt[3] = {0.f, 0.f, 0.f};  // the untransformed point (SRC 0), carried next to its record for the backward
@@ -82,17 +83,27 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
   }
   if (present && !live && P.point_index != nullptr) src_i = 0;   // a skipped point: an out-of-bounds record at a valid source index
   const int bin = rec.code < 0 ? D : (rec.code >> 20);
-  __syncthreads();  // the masks are zeroed (the transform above ran under that latency)
-  if (present) atomicOr(&member[bin * MW + (tid >> 5)], 1u << (tid & 31));
+  // the lanes of this wave that hold a point of the same bin: one ballot per bit of the bin number
+  const int wave = tid / DPC_WAVE;
+  unsigned long long same = __ballot(present);
+  for (int bit = 0; (nbins - 1) >> bit; ++bit) {   // block-uniform trip count: the bits of the largest bin number
+    const bool mine = (bin >> bit) & 1;
+    const unsigned long long has = __ballot(mine);
+    same &= mine ? has : ~has;
+  }
+  const int below = __builtin_amdgcn_mbcnt_hi((unsigned int)(same >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)same, 0u));
+  __syncthreads();  // the counts are zeroed (the transform above ran under that latency)
+  if (present && below == 0) cnt[wave * nbins + bin] = __popcll(same);   // the group's first lane
   __syncthreads();
 
-  // exclusive prefix over the bin populations by the first wave: lane l owns bins [l*C, (l+1)*C)
+  // start positions by the first wave: lane l owns bins [l*C, (l+1)*C); cnt[w][k] becomes the first sorted position of the
+  // points of bin k that sit in wave w (waves in order inside a bin: stable)
   if (tid < DPC_WAVE) {
     const int C = (nbins + DPC_WAVE - 1) / DPC_WAVE;
     auto population = [&](int k) {
       int n = 0;
 #pragma unroll
-      for (int wd = 0; wd < MW; ++wd) n += __popc(member[k * MW + wd]);
+      for (int w = 0; w < NW; ++w) n += cnt[w * nbins + k];
       return n;
     };
     int sum = 0;
@@ -105,23 +116,21 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
     }
     int run = incl - sum;
     for (int k = tid * C; k < min((tid + 1) * C, nbins); ++k) {
-      hist[k] = run;
-      run += population(k);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const int c = cnt[w * nbins + k];
+        cnt[w * nbins + k] = run;
+        run += c;
+      }
     }
-    if (tid == DPC_WAVE - 1) hist[nbins] = incl;  // total
+    if (tid == DPC_WAVE - 1) total_pts = incl;
   }
   __syncthreads();
 
   // sorted chunk staged in LDS, then copied out with one coalesced 16-byte store per lane and array
   __shared__ int4 stage[2 * kLocThreads];
   if (present) {
-    int below = 0;  // members of this bin with a smaller thread id
-#pragma unroll
-    for (int wd = 0; wd < MW; ++wd) {
-      const unsigned int m = member[bin * MW + wd];
-      below += __popc(wd < (tid >> 5) ? m : (wd == (tid >> 5) ? (m & ((1u << (tid & 31)) - 1u)) : 0u));
-    }
-    const int pos = hist[bin] + below;
+    const int pos = cnt[wave * nbins + bin] + below;   // bin start of this wave's group + rank inside the group
     int4 v;
     v.x = rec.code; v.y = __float_as_int(rec.tz); v.z = __float_as_int(rec.ty); v.w = __float_as_int(rec.tx);
     stage[pos] = v;
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
     reinterpret_cast<int4*>(out + (size_t)kLocThreads * sizeof(PointRec))[tid] = stage[kLocThreads + tid];
   }
   uint16_t* offs = reinterpret_cast<uint16_t*>(out + (size_t)kLocThreads * 2 * sizeof(PointRec));
-  for (int k = tid; k < nbins + 1; k += kLocThreads) offs[k] = (uint16_t)hist[k];
+  for (int k = tid; k < nbins + 1; k += kLocThreads) offs[k] = (uint16_t)(k < nbins ? cnt[k] : total_pts);   // cnt[0][k]: the bin's start
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -514,7 +523,7 @@ int launch_locate(const DpcParams* p, int src, const void* pts, const float* q, 
   if (p->N == 0 || p->B == 0) return DPC_OK;
   dim3 g(num_chunks(p->N) * p->B), blk(kLocThreads);
   uint8_t* out = static_cast<uint8_t*>(cells);
-  const size_t lds = (size_t)(p->D + 1) * (kLocThreads / 32) * sizeof(unsigned int);  // the bins' membership masks
+  const size_t lds = (size_t)(p->D + 1) * (kLocThreads / DPC_WAVE) * sizeof(int);  // group sizes / start positions per wave and bin
   if (src == 0) DPC_LAUNCH("k_locate", k_locate<0>, g, blk, lds, st, *p, pts, q, t, f, tr_pc, out);
   else if (src == 1) DPC_LAUNCH("k_locate", k_locate<1>, g, blk, lds, st, *p, pts, q, t, f, tr_pc, out);
   else DPC_LAUNCH("k_locate", k_locate<2>, g, blk, lds, st, *p, pts, q, t, f, tr_pc, out);
