@@ -38,6 +38,10 @@ extern "C" {
 
 #define DPC_ABI_VERSION 13
 #define DPC_MAX_TAPS 63 /* longest 1-D smoothing kernel accepted (pc_gauss_kernel_size) */
+/* Size limits, checked by every entry point (DPC_ERR_SHAPE): grid sides <= 1024 (10-bit cell indices in a point record),
+ * B <= 65535, and N <= DPC_MAX_POINTS points per cloud: a voxel's splat weights are summed in 64-bit fixed point with 44
+ * fractional bits, so 2^20 - 1 points of weight 1 in ONE voxel is the most that cannot wrap. */
+#define DPC_MAX_POINTS 1048575
 
 enum {
   DPC_OK = 0,
@@ -59,7 +63,7 @@ enum {
  * read at dpc/util/point_cloud_to.py:11-15,128-135; dpc/util/drc.py:52-57,148). */
 typedef struct DpcParams {
   int32_t B;               /* clouds in this call (batch_size * step_size * num_candidates)            */
-  int32_t N;               /* points per cloud                                                          */
+  int32_t N;               /* points per cloud, <= DPC_MAX_POINTS                                       */
   int32_t D, H, W;         /* voxel grid                                                                */
   int32_t taps_xy;         /* length of the x/y Gaussian (odd), 0 = no smoothing (kernel=None / CPU branch) */
   int32_t taps_z;          /* length of the z Gaussian (odd), 0 = no smoothing                          */

@@ -347,6 +347,7 @@ using BwdGeo = SlabGeo<GS, RB, bwd_threads(GS, NPL), 32, (GS == 128 ? 8 : 16)>;
 constexpr float kFixScale = 17592186044416.0f;          // 2^44: splat weights accumulate as 64-bit fixed point
 constexpr float kFixInv = 1.0f / 17592186044416.0f;
 constexpr unsigned long long kFixOne = 1ull << 44;
+static_assert((unsigned long long)DPC_MAX_POINTS <= ~0ull / kFixOne, "DPC_MAX_POINTS unit weights must fit the 64-bit accumulator");
 
 // Conversions between fp32 and the 64-bit fixed point, written on the two 32-bit halves.  Left as `(unsigned long long)(w *
 // 2^44)` and `(float)(a >> 32) ...` the compiler expands generic 64-bit <-> float conversions (it widens the halves back to
@@ -662,6 +663,7 @@ inline int validate(const DpcParams* p) {
   if (p == nullptr) return DPC_ERR_NULL;
   if (p->B < 0 || p->N < 0 || p->D < 1 || p->H < 1 || p->W < 1) return DPC_ERR_SHAPE;
   if (p->D > 1024 || p->H > 1024 || p->W > 1024 || p->B > 65535) return DPC_ERR_SHAPE;  // 10-bit cell indices
+  if (p->N > DPC_MAX_POINTS) return DPC_ERR_SHAPE;   // one voxel's fixed-point sum (kFixOne = 2^44 per unit weight) must not wrap
   if (p->point_replicas < 0 || (p->point_replicas > 1 && p->B % p->point_replicas != 0)) return DPC_ERR_SHAPE;
   if (p->point_index != nullptr && p->N_src < 1) return DPC_ERR_SHAPE;
   if ((p->dev_taps_xy != nullptr && p->taps_xy < 1) || (p->dev_taps_z != nullptr && p->taps_z < 1)) return DPC_ERR_TAPS;

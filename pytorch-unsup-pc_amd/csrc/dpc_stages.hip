@@ -378,7 +378,7 @@ const char* dpc_strerror(int code) {
   switch (code) {
     case DPC_OK: return "ok";
     case DPC_ERR_NULL: return "a required pointer is NULL";
-    case DPC_ERR_SHAPE: return "B/N/D/H/W out of range";
+    case DPC_ERR_SHAPE: return "B/N/D/H/W out of range (B <= 65535, N <= 1048575 points per cloud, grid sides 1..1024)";
     case DPC_ERR_TAPS: return "smoothing kernel length must be odd and <= DPC_MAX_TAPS (fused path: effective radius <= 15)";
     case DPC_ERR_LDS: return "an H x W plane does not fit the 160 KiB LDS tile";
     case DPC_ERR_LAUNCH: return "HIP kernel launch failed";

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("DPC_RENDER_LIB") or os.path.join(_CSRC, "libdpc_rende
 
 ABI_VERSION = 13
 DPC_MAX_TAPS = 63
+DPC_MAX_POINTS = (1 << 20) - 1
 DPC_SMALL_COLS = 12
 COL_DQ, COL_DS, COL_DT, COL_DF = 0, 4, 5, 8
 DPC_ERR_SHAPE = -2

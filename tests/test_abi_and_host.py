@@ -52,6 +52,14 @@ def test_size_queries_and_validation_without_gpu():
     assert ws >= 32 * 64 ** 3 * 4 and ws % 256 == 0
     bad = _native.DpcParams(1, 10, 2048, 64, 64, 0, 0, 2.0, 1.875, 1e-5, 10.0, 1)  # D beyond the 10-bit cell index
     assert L.dpc_workspace_bytes(ctypes.byref(bad)) == 0
+    # ... and a cloud of 2^20 points could wrap one voxel's 64-bit fixed-point sum: refused, 2^20 - 1 is the most
+    many = _native.DpcParams(1, _native.DPC_MAX_POINTS + 1, 64, 64, 64, 0, 0, 2.0, 1.875, 1e-5, 10.0, 1)
+    assert L.dpc_cells_bytes(ctypes.byref(many)) == 0 and L.dpc_check_grid(ctypes.byref(many), 1) == _native.DPC_ERR_SHAPE
+    most = _native.DpcParams(1, _native.DPC_MAX_POINTS, 64, 64, 64, 0, 0, 2.0, 1.875, 1e-5, 10.0, 1)
+    assert L.dpc_cells_bytes(ctypes.byref(most)) == 4096 * (256 * 32 + 144) and L.dpc_check_grid(ctypes.byref(most), 1) == 0
+    assert "1048575" in _native.strerror(_native.DPC_ERR_SHAPE)
+    header = open(os.path.join(ROOT, "include", "dpc_render.h")).read()
+    assert "#define DPC_MAX_POINTS %d" % _native.DPC_MAX_POINTS in header
     # argument validation happens before any launch: NULL pointers / even tap counts are refused on CPU too
     assert L.dpc_project_fwd(ctypes.byref(P), *([None] * 16)) == -1  # 16 pointer arguments
     even = _native.DpcParams(1, 10, 16, 16, 16, 4, 4, 2.0, 1.875, 1e-5, 10.0, 1)

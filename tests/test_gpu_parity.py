@@ -634,6 +634,48 @@ def test_full_size_properties(R, O):
     close(g1[2][idx], cs.grad, TOL, "ds vs oracle at full size")
 
 
+@pytest.mark.parametrize("path,B,chunk", [("plain", 4352, 128), ("fused", 8192, 128)])
+def test_batches_whose_grids_pass_4_gib(R, O, path, B, chunk):
+    """Maximum sizes: a batch whose intermediate grids (B x 64^3 fp32: 4.6 GB / 8.6 GB each) lie beyond 32-bit byte AND, at
+    8192 clouds, 32-bit element offsets.  The oracle cannot run at that size; the property is batch independence, exact: every
+    cloud's silhouette and gradients are bit for bit what the same cloud gives in a batch of 128 (fixed-order sums and integer
+    accumulation make results independent of the company a cloud keeps; the fused loss's 1/B is a power of two in both runs)."""
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 << 30:
+        pytest.skip("needs 60 GB of free device memory")
+    N, G = 300, 64
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=21)
+    kern = R.smoothing_kernel(cfg, 0.64)
+    g = torch.Generator().manual_seed(77)
+    pc = (torch.tanh(0.5 * torch.randn(B, N, 3, generator=g)) / 2).cuda().requires_grad_(True)
+    q = torch.randn(B, 4, generator=g).cuda().requires_grad_(True)
+    s = (0.5 + 0.5 * torch.rand(B, 1, generator=g)).cuda().requires_grad_(True)
+    gt = (torch.rand(B, G, G, 1, generator=g) > 0.5).float().cuda()
+
+    def run(lo, hi):
+        a, b, c = (x[lo:hi].detach().clone().requires_grad_(True) for x in (pc, q, s))
+        if path == "plain":
+            proj = R.pointcloud_project_fast(cfg, a, b, None, None, kern, scaling_factor=c)["proj"]
+            (proj * (gt[lo:hi] - 0.5)).sum().backward()
+        else:
+            loss, out, _ = R.pointcloud_project_loss(cfg, a, b, None, None, kern, scaling_factor=c, gt=gt[lo:hi])
+            loss.backward()
+            proj = out["proj"]
+        return proj.detach(), a.grad, b.grad, c.grad
+
+    whole = run(0, B)
+    torch.cuda.synchronize()
+    scale = 1.0 if path == "plain" else float(B) / chunk     # d(loss) carries 1/B: 1/8192 against 1/128
+    assert all(torch.isfinite(t).all() for t in whole)
+    assert float(whole[1].abs().max()) > 0 and float(whole[2].abs().max()) > 0
+    for lo in list(range(0, B, chunk))[::7] + [B - chunk]:    # every seventh batch of 128 and the last one
+        part = run(lo, lo + chunk)
+        for name, w, p_, k in zip(("proj", "dpc", "dq", "ds"), whole, part, (1.0, scale, scale, scale)):
+            assert torch.equal(w[lo:lo + chunk] * k, p_), "%s of clouds %d..%d depends on the batch (%s path, B=%d)" % (name, lo, lo + chunk, path, B)
+    del whole
+    torch.cuda.empty_cache()
+
+
 def test_benchmarked_call_at_full_size(R, O):
     """The call bench.py times, at the size it times it: pointcloud_project_loss with one pose candidate per sample (the
     ray-march kernel runs the column backward inside the forward, the loss is summed in 64-bit fixed point), B=32, N=8000,
@@ -1304,6 +1346,41 @@ def test_many_chunks_fallback_iteration(R, O):
     close(gp.grad, cp.grad, TOL, "dpc (N=20000)")
     close(gq.grad, cq.grad, TOL, "dq (N=20000)")  # a sum over 20000 points in fp32
     close(gs.grad, cs.grad, TOL, "ds (N=20000)")
+
+
+def test_the_most_points_a_cloud_may_have(R, O):
+    """N = DPC_MAX_POINTS = 2^20 - 1 (one more could wrap a voxel's 64-bit fixed-point sum; the library refuses it).  All of them
+    in ONE voxel: the sum is exact.  A random cloud of that size (4096 sorted chunks) against the oracle, forward and backward."""
+    from dpc.render import _native
+    N, G = _native.DPC_MAX_POINTS, 64
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=21)
+    corner = torch.full((1, N, 3), -0.5, device="cuda")
+    raw, _ = R.pointcloud2voxels3d_fast(cfg, corner, None)
+    assert float(raw[0, 0, 0, 0]) == float(N) and float(raw.double().sum()) == float(N)
+    proj = R.pointcloud_project_fast(cfg, corner.requires_grad_(True), torch.tensor([[1.0, 0, 0, 0]], device="cuda"), None, None,
+                                     R.smoothing_kernel(cfg, 0.64))["proj"]
+    assert torch.isfinite(proj).all()
+    with pytest.raises(RuntimeError, match="out of range"):
+        R.pointcloud2voxels3d_fast(cfg, torch.zeros(1, N + 1, 3, device="cuda"), None)
+    del corner, raw, proj
+
+    g = torch.Generator().manual_seed(4)
+    pc = torch.tanh(0.5 * torch.randn(1, N, 3, generator=g)) / 2
+    pc[:, ::3] *= 1.9          # a third of the points far out: sparse rims whose voxels stay below the clamp
+    q, s = torch.randn(1, 4, generator=g), torch.full((1, 1), 0.001)
+    gt = (torch.rand(1, G, G, 1, generator=g) > 0.5).float()
+    leaf = lambda x: x.clone().requires_grad_(True)
+    cp, cq, cs = leaf(pc), leaf(q), leaf(s)
+    ref = O.pointcloud_project_fast(cfg, cp, cq, None, None, O.smoothing_kernel(cfg, 0.64), scaling_factor=cs)
+    ((ref["proj"] - gt) ** 2).sum().backward()
+    gp, gq, gs = dev(pc, True), dev(q, True), dev(s, True)
+    loss, out, _ = R.pointcloud_project_loss(cfg, gp, gq, None, None, R.smoothing_kernel(cfg, 0.64), scaling_factor=gs, gt=dev(gt))
+    loss.backward()
+    close(out["proj"], ref["proj"], TOL, "proj (N=2^20-1)")
+    close(gs.grad, cs.grad, TOL, "ds (N=2^20-1)")
+    close(gq.grad, cq.grad, TOL, "dq (N=2^20-1)")
+    close(gp.grad, cp.grad, TOL, "dpc (N=2^20-1)")
+    assert float(cp.grad.abs().max()) > 0 and float(cq.grad.abs().max()) > 0
 
 
 def test_empty_clouds_through_fused_path(R, O):
