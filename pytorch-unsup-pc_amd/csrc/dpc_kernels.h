@@ -315,9 +315,23 @@ __device__ inline void store_through(f32x2* p, f32x2 v) {
 }
 constexpr int kAuxThrough = 16;   // the same bit for the raw-buffer store builtins (cache policy operand: sc1)
 
-template <int GS, int RB, int NT_, int LW_, int LH_>
+#ifndef DPC_BWD_NARROW_PAD
+#define DPC_BWD_NARROW_PAD 1
+#endif
+constexpr bool kBwdNarrowPad = DPC_BWD_NARROW_PAD != 0;   // 64-wide thick backward slabs at radius > 4: see BwdGeo
+#ifndef DPC_BWD_ZS64
+#define DPC_BWD_ZS64 8
+#endif
+constexpr int kBwdZs64 = DPC_BWD_ZS64;   // cell layers of the thick backward slab at G = 64 (the other thicknesses: further down)
+
+// PADO >= 0 fixes the zero pad between rows (the backward's narrow layout, see BwdGeo); -1: as wide as the tap radius
+template <int GS, int RB, int NT_, int LW_, int LH_, int PADO = -1>
 struct SlabGeo {
-  static constexpr int PAD = RB <= 4 ? 4 : ((RB + 3) / 4) * 4;
+  static constexpr int PAD = PADO >= 0 ? PADO : (RB <= 4 ? 4 : ((RB + 3) / 4) * 4);
+  // NARROW: the pad is shorter than the radius, so a point's W window can reach into the neighbouring rows (or LEAD floats in
+  // front of the first row / behind the last): the reader masks those taps itself and the LEAD floats are kept zero
+  static constexpr bool NARROW = PAD < RB;
+  static constexpr int LEAD = NARROW ? ((RB + 1 - PAD + 3) / 4) * 4 : 0;   // a window reaches RB in front of a row, RB + 1 behind it
   static constexpr int WP = GS + PAD;
   // row stride of the forward's 64-bit accumulators (u64 units).  GS + PAD is a multiple of 4, i.e. 8 mod 16 dwords:
   // lanes that walk rows with ds_read_b128 then use only every other group of four banks (2-way conflict in every
@@ -328,8 +342,9 @@ struct SlabGeo {
   static constexpr int LW = LW_, NSEGW = GS / LW, LWIN = LW + 2 * PAD;              // W-pass
   static constexpr int LH = LH_, NSEGH = GS / LH, XP = GS / 2, HWIN = LH + 2 * RB;  // H-pass
   static constexpr int NT = NT_;
-  __host__ __device__ static constexpr size_t slab_floats(int planes) { return (size_t)planes * PLANE + PAD; }
-  __device__ static int at(int z, int y, int x) { return (z * GS + y) * WP + PAD + x; }
+  __host__ __device__ static constexpr size_t slab_floats(int planes) { return (size_t)planes * PLANE + PAD + 2 * LEAD; }
+  __device__ static int at(int z, int y, int x) { return LEAD + (z * GS + y) * WP + PAD + x; }
+  __device__ static int row_start(int row) { return LEAD + row * WP; }   // the row's pad; its first voxel PAD floats on
 };
 // forward: ZS planes, 16 voxels per thread, short segments so that every thread owns exactly one W and one H item
 template <int GS, int ZS, int RB>
@@ -342,7 +357,10 @@ constexpr int bwd_threads(int gs, int npl) {
 template <int GS, int RB, int NPL>
 // 128-wide planes: 8-row H-pass segments -- a one-plane step of the rolling backward then has an item for every one of
 // its 1024 threads (16-row segments left half of them idle under a latency-bound load: k_gather_hw<128,1,8> 41.9 -> 38.7 us)
-using BwdGeo = SlabGeo<GS, RB, bwd_threads(GS, NPL), 32, (GS == 128 ? 8 : 16)>;
+// 64-wide planes, radius > 4: pads of 4 whatever the radius -- with pads as wide as the radius (8, 12 floats per row) a
+// workgroup's LDS held 3 + 1 planes at best (8 + 1 need 166 / 175 KB), 22 slabs per cloud instead of 8; the gather masks the
+// taps that would reach over a row's end instead (k_gather_hw, corner_row)
+using BwdGeo = SlabGeo<GS, RB, bwd_threads(GS, NPL), 32, (GS == 128 ? 8 : 16), (GS == 64 && RB > 4 && NPL == kBwdZs64 + 1 && kBwdNarrowPad ? 4 : -1)>;
 
 constexpr float kFixScale = 17592186044416.0f;          // 2^44: splat weights accumulate as 64-bit fixed point
 constexpr float kFixInv = 1.0f / 17592186044416.0f;
@@ -725,19 +743,24 @@ inline Cells cells_view(const DpcParams* p, const void* cells) {
 #define DPC_FWD_ZS64 4
 #endif
 constexpr int kFwdZs64 = DPC_FWD_ZS64;
-#ifndef DPC_BWD_ZS64
-#define DPC_BWD_ZS64 8
+// Cell layers per backward slab at G = 64.  THICK: 8 + 1 planes fill the LDS, one 1024-thread workgroup per CU, 8 slabs per cloud:
+// the best shape whenever (clouds with backward work) x 8 fills the chip -- 32 clouds are exactly one round of 256 workgroups
+// (8: 17.0-17.7, 4: 22.8-23.1, 3: 21.2-21.3, 2: 25.8-26.4 us at c2, radius 3).  At radius 5..10 the thick slab fits because
+// its rows carry pads of 4, not of the radius (BwdGeo's narrow layout: k_gather_hw masks the taps that reach over a row's end);
+// with pads as wide as the radius 3 + 1 planes was the best that fit (22 slabs per cloud, two workgroups per CU):
+// sigma_rel 0.9 / 1.2 / 3.0: 23.0 / 25.9 / 27.1 -> 19.2 / 21.7 / 24.1 us (profiles/r04_ab/narrow_pad_*.jsonl).
+// THIN: when the thick slabs would leave CUs empty (c5: 16 winning clouds of 128 = 128 workgroups) thinner ones win:
+// radius 3, 16 clouds: 4 layers 13.6 us against 8: 15.5 (3: 14.7, 2: 15.4); radius 10, 16 clouds: 3 layers with wide pads 20.0
+// against 8 narrow 23.8.  launch_gather_rb picks per call.
+#ifndef DPC_BWD_ZS64_THIN
+#define DPC_BWD_ZS64_THIN 4
 #endif
 #ifndef DPC_BWD_ZS64_WIDE
 #define DPC_BWD_ZS64_WIDE 3
 #endif
-// The same at tap radius 5..10, where a row carries 12 pad floats and 7 + 1 planes would fill the LDS: that is 10 slabs per
-// cloud = 320 workgroups for 32 clouds, TWO rounds on 256 CUs (k_gather_hw<64,7,10> 32 us at sigma_rel 3.0, twice the
-// radius-3 kernel).  3 + 1 planes (78 KB, 512 threads) put two workgroups on a CU, whose load and gather phases overlap:
-// 27 us (4: 31.2, 5: 30.6; same box, alternating builds, profiles/r04_ab/).  At radius <= 4 the thin slabs lose (round 2).
-constexpr int kBwdZs64Wide = DPC_BWD_ZS64_WIDE;
-constexpr int kBwdZs64 = DPC_BWD_ZS64;  // cell layers per backward slab at G = 64 (8 -> 9 planes, 1 workgroup/CU; 3 -> 4 planes, 2/CU)  // planes per forward slab at G = 64 (4 -> 1 workgroup/CU, 2 -> 2 workgroups/CU)
-
+// kBwdZs64 (thick slab, every radius; narrow pads beyond radius 4): defined next to BwdGeo
+constexpr int kBwdZs64Thin = DPC_BWD_ZS64_THIN;  // few working clouds, radius <= 4
+constexpr int kBwdZs64Wide = DPC_BWD_ZS64_WIDE;  // few working clouds, radius 5..10 (pads as wide as the radius)
 
 // losing pose candidates of the fused min-of-K loss do no backward work
 __device__ inline bool cloud_loses(const LossArgs& la, int b) {

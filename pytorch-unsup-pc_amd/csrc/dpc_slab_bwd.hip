@@ -89,15 +89,17 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     DPC_STAMP(8);
     for (int i = tid; i < (NPL * GS + 1) * (Geo::PAD / 4); i += Geo::NT) {  // zero the row pads (W-pass halo)
       const int p4 = i % (Geo::PAD / 4), row = i / (Geo::PAD / 4);
-      *reinterpret_cast<f32x4*>(slab + row * Geo::WP + 4 * p4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      *reinterpret_cast<f32x4*>(slab + Geo::row_start(row) + 4 * p4) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    if constexpr (Geo::NARROW)   // ... and the floats a window can reach in front of the first row and behind the last pad
+      if (tid < 2 * Geo::LEAD) slab[tid < Geo::LEAD ? tid : Geo::row_start(NPL * GS) + Geo::PAD + tid - Geo::LEAD] = 0.f;
     if constexpr (RB == 0) {
       // planes -> LDS (16-byte global loads, 16-byte LDS stores); absent planes are zeroed
       for (int i = tid; i < NPL * GS * (GS / 4); i += Geo::NT) {
         const int x4 = i % (GS / 4), zy = i / (GS / 4);
         f32x4 val = f32x4{0.f, 0.f, 0.f, 0.f};
         if (zy < nzp * GS) val = *reinterpret_cast<const f32x4*>(src + (size_t)zy * GS + 4 * x4);
-        *reinterpret_cast<f32x4*>(slab + zy * Geo::WP + Geo::PAD + 4 * x4) = val;
+        *reinterpret_cast<f32x4*>(slab + Geo::row_start(zy) + Geo::PAD + 4 * x4) = val;
       }
       if (cells.nblk <= DPC_WAVE) finish_record_table(rr, reinterpret_cast<int*>(red + kRedTab));
       __syncthreads();
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
       for (int i = tid; i < NPL * GS * GS; i += Geo::NT) {
         const int x = i % GS, zy = i / GS;
         const bool pass = zy < nzp * GS && ((mask32[i >> 5] >> (i & 31)) & 1u);
-        float* cell = slab + zy * Geo::WP + Geo::PAD + x;
+        float* cell = slab + Geo::row_start(zy) + Geo::PAD + x;
         *cell = pass ? w2 * *cell : 0.f;
       }
       __syncthreads();
@@ -178,7 +180,27 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
   // with more records than threads starts with its loads answered -- measured 0.3-0.5 us slower: the pass is bound by its
   // arithmetic, 2.1-2.7 us per pass of four waves per SIMD, not by the two dependent loads in front of it.)
   // One (z, y) row of a point's cell: the adjoint W pass at its two x corners, masked (GS > 0, RB > 0 only).
-  auto corner_row = [&](const Cell& c, int k, int j, float& o0, float& o1) {
+  // Narrow layout (pads shorter than the radius): the taps of a point's window that fall outside its row AND beyond the row's
+  // zero pad -- there lies the neighbouring row, not zeros -- get weight zero, once per point for its four rows.  Only window
+  // positions within RB - PAD of the window's ends can do that (`reaches_over`), and only for points near the row's ends; the
+  // other taps keep their scalar weights.  wm[e][tp] is tap tp as seen from the point's x corner e (window position e + tp).
+  // (0 x finite = 0: exact.  Where d T is not finite the step has diverged anyway.)
+  auto reaches_over = [](int pos) constexpr {
+    constexpr int P4 = BwdGeo<(GS > 0 ? GS : 64), RB, ZS + 1>::PAD;
+    return pos < RB - P4 || pos >= RB + P4 + 1;
+  };
+  auto masked_taps = [&](const Cell& c, float (&wm)[2][2 * RB + 1]) {
+    constexpr int P4 = BwdGeo<(GS > 0 ? GS : 64), RB, ZS + 1>::PAD;
+#pragma unroll
+    for (int pos = 0; pos < 2 * RB + 2; ++pos) {
+      if (!reaches_over(pos)) continue;
+      // x = ix - RB + pos: in front of the row for the low positions (x >= 0 wanted), behind it for the high ones (x < GS)
+      const bool inside = pos < RB - P4 ? c.ix >= RB - pos : c.ix <= GS - 1 + RB - pos;
+      if (pos <= 2 * RB) wm[0][pos] = inside ? taps_adj.w[pos] : 0.f;
+      if (pos >= 1) wm[1][pos - 1] = inside ? taps_adj.w[pos - 1] : 0.f;
+    }
+  };
+  auto corner_row = [&](const Cell& c, int k, int j, float& o0, float& o1, const float (&wm)[2][2 * RB + 1]) {
     if constexpr (GS > 0 && RB > 0) {
       using Geo = BwdGeo<GS, RB, ZS + 1>;
       const uint32_t* mlds = reinterpret_cast<const uint32_t*>(red + kRedMask);
@@ -186,7 +208,7 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
       if ((c.iz + k < D) && (c.iy + j < GS)) {
         const int plane = kRolls ? ((c.iz - zfirst + k) & 1) : (c.iz - z0 + k);  // rolling: plane z lives in buffer (z - zfirst) & 1
         const int row = plane * GS + c.iy + j;
-        const float* rp = slab + row * Geo::WP + Geo::PAD + c.ix - RB;  // x = ix-RB .. ix+1+RB, pads are zero
+        const float* rp = slab + Geo::row_start(row) + Geo::PAD + c.ix - RB;  // x = ix-RB .. ix+1+RB; pads are zero
         float v[2 * RB + 2];
 #pragma unroll
         for (int i = 0; i < 2 * RB + 2; ++i) v[i] = rp[i];
@@ -197,7 +219,8 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
 #pragma unroll
           for (int i = 0; i < 2 * RB + 1; ++i) {
             const int tp = tap_edge_first<RB>(i);   // edges first, centre last (dpc_common.h)
-            acc = fmaf(taps_adj.w[tp], v[e + tp], acc);
+            if (Geo::NARROW && reaches_over(e + tp)) acc = fmaf(wm[e][tp], v[e + tp], acc);
+            else acc = fmaf(taps_adj.w[tp], v[e + tp], acc);
           }
           const int x = c.ix + e;
           const bool pass = x < GS && ((mlds[row * (GS / 32) + (x >> 5)] >> (x & 31)) & 1u);
@@ -235,10 +258,12 @@ __global__ __launch_bounds__(kSlabThreads) void k_gather_hw(DpcParams P, Cells c
     float cv[2][2][2];
     if constexpr (GS > 0 && RB > 0) {
       // adjoint W-pass evaluated right here, at the two x corners of each of the four (z,y) rows, then masked
+      float wm[2][2 * RB + 1];
+      if constexpr (BwdGeo<GS, RB, ZS + 1>::NARROW) masked_taps(c, wm);
 #pragma unroll
       for (int k = 0; k < 2; ++k)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) corner_row(c, k, j, cv[k][j][0], cv[k][j][1]);
+        for (int j = 0; j < 2; ++j) corner_row(c, k, j, cv[k][j][0], cv[k][j][1], wm);
     } else {
 #pragma unroll
       for (int k = 0; k < 2; ++k)
@@ -378,11 +403,17 @@ int launch_gather_rb(const DpcParams* p, Cells cells, const float* pc, const flo
                   int ntile, float* dpc, float* dsmall, double* cg_part, unsigned int* cg_count, const LossArgs& la,
                   hipStream_t st, unsigned long long* dpc_fixed) {
   if (p->H == p->W) {
+    // 64-wide: thick slabs when they fill the chip, thinner ones when few clouds have backward work (dpc_kernels.h, kBwdZs64)
+    const bool wo64 = winners_only(la) && (p->point_replicas > 1 || p->point_index != nullptr);  // the kernel's own test
+    const bool thick = (size_t)(wo64 ? p->B / la.K : p->B) * ((p->D + kBwdZs64 - 1) / kBwdZs64) >= (size_t)kNumCUs;
     if constexpr (RB <= 4) {
       if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
       if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
-      if (p->H == 64) return launch_gather_fast<64, kBwdZs64, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
+      if (p->H == 64 && thick) return launch_gather_fast<64, kBwdZs64, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
+      if (p->H == 64) return launch_gather_fast<64, kBwdZs64Thin, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
     } else if constexpr (RB <= 10) {
+      if constexpr (kBwdNarrowPad)
+        if (p->H == 64 && thick) return launch_gather_fast<64, kBwdZs64, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
       if (p->H == 64) return launch_gather_fast<64, kBwdZs64Wide, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);
       if (p->H == 128) return launch_gather_fast<128, 1, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);  // c4: sigma_rel 1.28 -> radius 8
       if (p->H == 32) return launch_gather_fast<32, 4, RB>(p, cells, pc, q, t, f, kxy, pxy, dT, mask, ds_part, ntile, dpc, dsmall, cg_part, cg_count, la, st, dpc_fixed);

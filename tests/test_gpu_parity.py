@@ -676,6 +676,42 @@ def test_batches_whose_grids_pass_4_gib(R, O, path, B, chunk):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("sigma_rel", [0.64, 0.9, 1.2, 3.0])
+def test_backward_slab_thickness_is_not_visible_in_the_results(R, O, sigma_rel):
+    """The 64-wide backward picks its slab per call: 8 cell layers (narrow row pads beyond tap radius 4, taps that reach over a
+    row's end masked) when the clouds fill the chip, 4 or 3 layers when few clouds have backward work.  A batch of 32 takes the
+    thick slabs, the same clouds in batches of 8 the thin ones: gradients equal to the rule against each other AND both against
+    the oracle; d(points) -- per-point arithmetic in the same order whatever the slab -- bit for bit."""
+    B, N, G = 32, 3000, 64
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=21)
+    kern = R.smoothing_kernel(cfg, sigma_rel)
+    pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 515)
+    q[::4] = torch.tensor([1.0, 0.0, 0.0, 0.0])       # every fourth cloud unrotated: its third coordinate is the grid's x ...
+    pc[:, ::5, 2] = pc[:, ::5, 2].sign() * 0.49      # ... and a fifth of its points sit 3 voxels from the x faces, where windows leave the row
+
+    def run(lo, hi):
+        a, b, c = dev(pc[lo:hi], True), dev(q[lo:hi], True), dev(s[lo:hi], True)
+        loss, out, _ = R.pointcloud_project_loss(cfg, a, b, None, None, kern, scaling_factor=c, gt=dev(gt[lo:hi]))
+        loss.backward()
+        return out["proj"].detach(), a.grad, b.grad, c.grad
+
+    whole = run(0, B)
+    for lo in (0, 8, 24):
+        part = run(lo, lo + 8)
+        assert torch.equal(whole[0][lo:lo + 8], part[0]), "silhouettes depend on the batch"
+        assert torch.equal(whole[1][lo:lo + 8] * 4, part[1]), "d(points) depends on the slab thickness"   # 1/32 against 1/8
+        close(whole[2][lo:lo + 8] * 4, part[2], 1e-6, "dq thick vs thin slabs")
+        close(whole[3][lo:lo + 8] * 4, part[3], 1e-6, "ds thick vs thin slabs")
+    idx = [4, 30]
+    cp, cq, cs = (x[idx].clone().requires_grad_(True) for x in (pc, q, s))
+    ref = O.pointcloud_project_fast(cfg, cp, cq, None, None, O.smoothing_kernel(cfg, sigma_rel), scaling_factor=cs)
+    (((ref["proj"] - gt[idx].double()) ** 2).sum() / B).backward()
+    close(whole[0][idx], ref["proj"], TOL, "proj vs oracle (thick slabs, sigma_rel %g)" % sigma_rel)
+    close(whole[1][idx], cp.grad, TOL, "dpc vs oracle (thick slabs, sigma_rel %g)" % sigma_rel)
+    close(whole[2][idx], cq.grad, TOL, "dq vs oracle (thick slabs, sigma_rel %g)" % sigma_rel)
+    close(whole[3][idx], cs.grad, TOL, "ds vs oracle (thick slabs, sigma_rel %g)" % sigma_rel)
+
+
 def test_benchmarked_call_at_full_size(R, O):
     """The call bench.py times, at the size it times it: pointcloud_project_loss with one pose candidate per sample (the
     ray-march kernel runs the column backward inside the forward, the loss is summed in 64-bit fixed point), B=32, N=8000,
