@@ -10,7 +10,7 @@ for variant in "$@"; do
   OUT=gpurun_out/pmc_$CONFIG; [ "$variant" != main ] && OUT=${OUT}_$variant
   rm -rf $OUT; mkdir -p $OUT
   if [ "$variant" != main ]; then export DPC_RENDER_LIB="$PWD/scratch/$variant/libdpc_render.so"; else unset DPC_RENDER_LIB; fi
-  BENCH="python3 bench.py --config $CONFIG --steps 30 --warmup 5 --no-cpu-baseline --no-extras --no-graph"
+  BENCH="python3 bench.py --config $CONFIG --steps 30 --warmup 5 --no-cpu-baseline --no-extras --no-graph $PMC_BENCH_ARGS"   # e.g. PMC_BENCH_ARGS="--sigma-rel 3.0"
   i=0
   for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU SQ_INSTS_LDS" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_INST_CYCLES_VMEM SQ_WAIT_ANY"; do
     i=$((i+1))
