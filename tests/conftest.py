@@ -34,6 +34,23 @@ def native_library():
     return lib
 
 
+@pytest.fixture(scope="session", autouse=True)
+def two_rank_runs(request, native_library, tmp_path_factory):
+    """The two-rank GPU runs of tests/test_multi_gpu.py, started HERE -- at the start of the session, before any test has
+    initialised the GPU in this process (a process that has must not start other programs on the GPU boxes) -- and only when
+    that test is among the selected ones and the node has a GPU.  {backend: [result files] | error text}."""
+    wanted = any("test_two_ranks_render_their_shards" in item.nodeid for item in request.session.items)
+    if not wanted:
+        return {}
+    import torch
+
+    if torch.cuda.device_count() < 1:   # counting devices does not initialise the GPU
+        return {}
+    import test_multi_gpu
+
+    return test_multi_gpu.launch_ranks(str(tmp_path_factory.mktemp("two_ranks")))
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np
