@@ -380,6 +380,24 @@ __device__ inline float wave_sum(float v) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// Inclusive prefix sum over the 64 lanes of a wave, on DPP-modified adds (six VALU instructions; six __shfl_up are six
+// ds_bpermute round trips through the LDS crossbar): Kogge-Stone inside the 16-lane rows (row_shr, lanes without a source add
+// 0), then row_bcast:15 hands rows 1 and 3 their left neighbour's total and row_bcast:31 hands rows 2 and 3 the total of the
+// lower half.
+template <int CTRL, int ROW_MASK>
+__device__ inline int dpp_move_int(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ inline int wave_inclusive_scan(int v) {
+  v += dpp_move_int<0x111, 0xf>(v);  // row_shr:1
+  v += dpp_move_int<0x112, 0xf>(v);  // row_shr:2
+  v += dpp_move_int<0x114, 0xf>(v);  // row_shr:4
+  v += dpp_move_int<0x118, 0xf>(v);  // row_shr:8   -> inclusive inside every row
+  v += dpp_move_int<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_move_int<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // Sum NV per-thread values over the block; result valid in thread 0.  red must hold NV * (blockDim/64) floats.
 // Wave shuffles, then lanes 0..NV-1 of wave 0 each add one value's per-wave partials (independent LDS reads
 // that pipeline), then thread 0 collects the NV results with shuffles -- no serial chain of LDS latencies.

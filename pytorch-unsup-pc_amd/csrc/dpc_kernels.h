@@ -188,12 +188,7 @@ __device__ inline RecordRange load_record_range(const Cells& cells, int b, int b
 __device__ inline void finish_record_table(const RecordRange& r, int* tab) {
   if (threadIdx.x >= DPC_WAVE) return;
   const int c = threadIdx.x;
-  int incl = r.cnt;
-#pragma unroll
-  for (int off = 1; off < DPC_WAVE; off <<= 1) {
-    const int up = __shfl_up(incl, off, DPC_WAVE);
-    if (c >= off) incl += up;
-  }
+  const int incl = wave_inclusive_scan(r.cnt);   // wave 0, all 64 lanes (lanes without a chunk hold 0)
   tab[c] = incl - r.cnt;               // exclusive prefix
   tab[DPC_WAVE + 1 + c] = r.beg;
   if (c == DPC_WAVE - 1) tab[DPC_WAVE] = incl;  // total

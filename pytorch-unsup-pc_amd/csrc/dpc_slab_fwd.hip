@@ -108,12 +108,7 @@ __global__ __launch_bounds__(kLocThreads) void k_locate(DpcParams P, const void*
     };
     int sum = 0;
     for (int k = tid * C; k < min((tid + 1) * C, nbins); ++k) sum += population(k);
-    int incl = sum;
-#pragma unroll
-    for (int off = 1; off < DPC_WAVE; off <<= 1) {
-      const int up = __shfl_up(incl, off, DPC_WAVE);
-      if (tid >= off) incl += up;
-    }
+    const int incl = wave_inclusive_scan(sum);
     int run = incl - sum;
     for (int k = tid * C; k < min((tid + 1) * C, nbins); ++k) {
 #pragma unroll
