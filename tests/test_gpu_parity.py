@@ -676,13 +676,16 @@ def test_batches_whose_grids_pass_4_gib(R, O, path, B, chunk):
     torch.cuda.empty_cache()
 
 
+@pytest.mark.parametrize("B,chunk", [(32, 8), (33, 3)])
 @pytest.mark.parametrize("sigma_rel", [0.64, 0.9, 1.2, 3.0])
-def test_backward_slab_thickness_is_not_visible_in_the_results(R, O, sigma_rel):
+def test_backward_slab_thickness_is_not_visible_in_the_results(R, O, sigma_rel, B, chunk):
     """The 64-wide backward picks its slab per call: 8 cell layers (narrow row pads beyond tap radius 4, taps that reach over a
     row's end masked) when the clouds fill the chip, 4 or 3 layers when few clouds have backward work.  A batch of 32 takes the
     thick slabs, the same clouds in batches of 8 the thin ones: gradients equal to the rule against each other AND both against
-    the oracle; d(points) -- per-point arithmetic in the same order whatever the slab -- bit for bit."""
-    B, N, G = 32, 3000, 64
+    the oracle; d(points) -- per-point arithmetic in the same order whatever the slab -- bit for bit.  (33 clouds: thick slabs
+    off the XCD-aware workgroup map, which wants a multiple of 8; the loss' 1/33 against 1/3 is not a power of two, so
+    that case compares to rounding.)"""
+    N, G = 3000 if B == 32 else 1200, 64
     cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=21)
     kern = R.smoothing_kernel(cfg, sigma_rel)
     pc, q, s, gt, _, _ = O.synth_inputs(B, N, G, 515)
@@ -696,12 +699,17 @@ def test_backward_slab_thickness_is_not_visible_in_the_results(R, O, sigma_rel):
         return out["proj"].detach(), a.grad, b.grad, c.grad
 
     whole = run(0, B)
-    for lo in (0, 8, 24):
-        part = run(lo, lo + 8)
-        assert torch.equal(whole[0][lo:lo + 8], part[0]), "silhouettes depend on the batch"
-        assert torch.equal(whole[1][lo:lo + 8] * 4, part[1]), "d(points) depends on the slab thickness"   # 1/32 against 1/8
-        close(whole[2][lo:lo + 8] * 4, part[2], 1e-6, "dq thick vs thin slabs")
-        close(whole[3][lo:lo + 8] * 4, part[3], 1e-6, "ds thick vs thin slabs")
+    k = B / chunk
+    for lo in (0, chunk, 3 * chunk):
+        part = run(lo, lo + chunk)
+        assert torch.equal(whole[0][lo:lo + chunk], part[0]), "silhouettes depend on the batch"
+        if B == 32:
+            assert torch.equal(whole[1][lo:lo + chunk] * k, part[1]), "d(points) depends on the slab thickness"   # 1/32 against 1/8
+        else:
+            close(whole[1][lo:lo + chunk] * k, part[1], 1e-6, "dpc thick vs thin slabs")
+        sums = 1e-6 if B == 32 else 3e-6   # per-slab fp32 wave sums grouped 8 ways or 22; x 11 instead of x 4 on top for 33 clouds
+        close(whole[2][lo:lo + chunk] * k, part[2], sums, "dq thick vs thin slabs")
+        close(whole[3][lo:lo + chunk] * k, part[3], sums, "ds thick vs thin slabs")
     idx = [4, 30]
     cp, cq, cs = (x[idx].clone().requires_grad_(True) for x in (pc, q, s))
     ref = O.pointcloud_project_fast(cfg, cp, cq, None, None, O.smoothing_kernel(cfg, sigma_rel), scaling_factor=cs)
