@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU box: the fused loss call and the reference-signature call against the oracle over
+random shapes (clouds, points, grid side, a z side of its own, tap count, sigma, pose candidates, shared point sets,
+translation / focal-length inputs, which inputs need gradients).  Prints every case's worst error / bound ratio
+(bound = 1e-5 * max(1, max|ref|), the rule of tests/test_gpu_parity.py) and exits 1 if any exceeds 1.
+
+    python tools/fuzz_parity.py [cases=60] [seed=0] [only these case numbers, comma-separated]
+
+A case over the rule is looked at once more: the voxels the device put on the other side of the DRC clamp's thresholds are
+listed from the two `voxels` outputs, the oracle is re-run with exactly those voxels nudged to the device's side, and the case
+is judged against that (and says so).
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "pytorch-unsup-pc_amd")):
+    sys.path.insert(0, p)
+import numpy as np
+import torch
+
+import dpc.render as R
+from oracle import dpc_oracle as O
+
+O.EXACT_POSE_GRADIENT = True   # d(q) against the exact sum (tests/test_gpu_parity.py explains the two references)
+TOL = 1e-5
+
+
+def ratio(dev, ref):
+    ref = ref.detach().double()
+    err = float((dev.detach().double().cpu() - ref).abs().max()) if ref.numel() else 0.0
+    return err / (TOL * max(1.0, float(ref.abs().max()) if ref.numel() else 0.0))
+
+
+def threshold_nudge(cfg, ref_vox, dev_vox):
+    """The voxels the device decided the other way at the DRC clamp's thresholds (dpc/util/drc.py:57: clamp(v, eps, 1 - eps)
+    switches a voxel's gradient on or off; the fp64 oracle and the fp32 device -- whose Gaussians also drop taps below 1e-8
+    of the kernel's mass -- can disagree on a voxel that sits at eps or 1 - eps to a few parts in a thousand).  Returns
+    (number of such voxels, largest relative distance of one of them from its threshold, the O.DRC_CLAMP_NUDGE tensor that
+    puts exactly those voxels on the device's side: a 1e-9 relative step over the threshold, invisible forward)."""
+    eps = cfg.drc_logsum_clip_val
+    v, d = ref_vox.detach().double(), dev_vox.detach().double().cpu()
+    nudge = torch.zeros_like(v)
+    flips, far = 0, 0.0
+    for th, inside_is_above in ((eps, True), (1.0 - eps, False)):
+        ref_in = (v >= th) if inside_is_above else (v <= th)
+        dev_in = (d >= th) if inside_is_above else (d <= th)
+        diff = ref_in != dev_in
+        if diff.any():
+            flips += int(diff.sum())
+            far = max(far, float(((v[diff] - th).abs() / th).max()))
+            step = th * 1e-9 * (1.0 if inside_is_above else -1.0)          # towards the inside of [eps, 1 - eps]
+            target = torch.where(dev_in, torch.full_like(v, th + step), torch.full_like(v, th - step))
+            nudge = torch.where(diff, target - v, nudge)
+    return flips, far, nudge
+
+
+def one_case(seed, idx, rng=None, dry=False):
+    sequential = rng is not None          # the first version of this tool drew all cases from one stream (kept to replay its cases)
+    if rng is None:
+        rng = np.random.default_rng([seed, idx])
+    G = int(rng.choice([16, 24, 32, 48, 64, 64]))
+    ksz = int(rng.choice([1, 5, 11, 21, 21]))
+    sig = float(rng.uniform(0.25, 3.2)) if ksz > 1 else 0.5
+    K = int(rng.choice([1, 1, 2, 4]))
+    S = int(rng.integers(1, 7)) if rng.integers(0, 5) else int(rng.integers(8, 13))   # one case in five: enough clouds for the thick backward slabs
+    B = S * K
+    shared = K > 1 and bool(rng.integers(0, 2))        # the candidates of a sample share its point set
+    N = int(rng.integers(1, 2500))
+    with_t, with_f = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0)
+    vz = int(rng.choice([G, G, G, max(8, G // 2)]))
+    cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=ksz)
+    if vz != G:
+        cfg.vox_size_z = vz
+    data_seed = int(rng.integers(0, 1 << 30))
+    pc = O.synth_inputs(S if shared else B, N, G, data_seed)[0]
+    if rng.integers(0, 3) == 0:
+        pc = pc * 1.5                                   # a good share of the points outside the grid
+    _, q, s, _, t, f = O.synth_inputs(B, 4, G, data_seed + 1, with_t=with_t, with_f=with_f)
+    gt = O.synth_inputs(S, 1, G, data_seed + 2)[3]      # the silhouette is H x W whatever the depth
+    w = torch.from_numpy((np.random.default_rng([seed, idx]) if sequential and shared else rng).standard_normal((B, G, G, 1)))
+    if dry:
+        return None, None, None
+    label = "case %3d: G=%d%s k=%d sigma=%.2f S=%d K=%d%s N=%d%s%s" % (
+        idx, G, "" if vz == G else " z=%d" % vz, ksz, sig, S, K, " shared" if shared else "", N, " t" if with_t else "", " f" if with_f else "")
+    leaf = lambda x: None if x is None else x.clone().requires_grad_(True)
+    kern = O.smoothing_kernel(cfg, sig)
+    d = lambda x: None if x is None else x.float().cuda().requires_grad_(True)
+    cu = lambda x: None if x is None else x.float().cuda()
+
+    # device: the fused loss call, and the reference's own signature with a weighted sum of the silhouette as the loss
+    gp, gq, gs, gtt, gf = d(pc), d(q), d(s), d(t), d(f)
+    loss, out, win = R.pointcloud_project_loss(cfg, gp, gq, gtt, None, R.smoothing_kernel(cfg, sig), scaling_factor=gs, focal_length=gf,
+                                               gt=gt.float().cuda(), num_candidates=K)
+    loss.backward()
+    gp2, gq2, gs2 = d(pc), d(q), d(s)
+    o2 = R.pointcloud_project_fast(cfg, gp2.repeat_interleave(K, 0) if shared else gp2, gq2, cu(t), None, R.smoothing_kernel(cfg, sig),
+                                   scaling_factor=gs2, focal_length=cu(f))
+    (o2["proj"] * w.float().cuda()).sum().backward()
+    dev_vox = o2["voxels"].detach()
+
+    def against_the_oracle(nudge):
+        O.DRC_CLAMP_NUDGE = nudge
+        try:
+            cp, cq, cs, ct, cf = leaf(pc), leaf(q), leaf(s), leaf(t), leaf(f)
+            ref = O.pointcloud_project_fast(cfg, cp.repeat_interleave(K, 0) if shared else cp, cq, ct, None, kern, scaling_factor=cs, focal_length=cf)
+            rloss, rwin = O.proj_loss_pose_candidates(gt, ref["proj"], K) if K > 1 else (((ref["proj"] - gt) ** 2).sum() / B, None)
+            rloss.backward()
+            cp2, cq2, cs2 = leaf(pc), leaf(q), leaf(s)
+            ref2 = O.pointcloud_project_fast(cfg, cp2.repeat_interleave(K, 0) if shared else cp2, cq2, t, None, kern, scaling_factor=cs2, focal_length=f)
+            (ref2["proj"] * w).sum().backward()
+        finally:
+            O.DRC_CLAMP_NUDGE = None
+        rs = {"loss": ratio(loss, rloss), "proj": ratio(out["proj"], ref["proj"]), "dpc": ratio(gp.grad, cp.grad), "dq": ratio(gq.grad, cq.grad),
+              "ds": ratio(gs.grad, cs.grad)}
+        if with_t:
+            rs["dt"] = ratio(gtt.grad, ct.grad)
+        if with_f:
+            rs["df"] = ratio(gf.grad, cf.grad)
+        if K > 1 and not np.array_equal(win.cpu().numpy(), rwin.numpy()):
+            rs["winners"] = float("inf")
+        rs.update({"plain proj": ratio(o2["proj"], ref2["proj"]), "plain dpc": ratio(gp2.grad, cp2.grad), "plain dq": ratio(gq2.grad, cq2.grad),
+                   "plain ds": ratio(gs2.grad, cs2.grad), "plain voxels": ratio(o2["voxels"], ref2["voxels"])})
+        return rs, ref2["voxels"]
+
+    rs, ref_vox = against_the_oracle(None)
+    notes = []
+    if max(rs.values()) > 1.0:
+        flips, far, nudge = threshold_nudge(cfg, ref_vox, dev_vox)
+        if flips:
+            rs2, _ = against_the_oracle(nudge)
+            notes.append("un-nudged oracle: worst %s %.3f; %d voxel(s) decided the other way at the DRC clamp's threshold (within %.1e relative "
+                         "of it); against the oracle with THOSE voxels on the device's side:" % (max(rs, key=rs.get), max(rs.values()), flips, far))
+            rs = rs2
+    return label, rs, notes
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    only = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else range(cases)
+    worst, bad, explained, t0 = {}, 0, 0, time.time()
+    stream = np.random.default_rng(seed) if os.environ.get("FUZZ_SEQUENTIAL_STREAM") else None
+    for i in (range(max(only) + 1) if stream is not None else only):
+        label, rs, notes = one_case(seed, i, stream, dry=stream is not None and i not in only)
+        if label is None:
+            continue
+        explained += bool(notes)
+        top = max(rs, key=rs.get)
+        flag = "" if rs[top] <= 1.0 else "   <-- OVER THE RULE"
+        bad += bool(flag)
+        for x in notes:
+            print("%s: %s" % (label, x), flush=True)
+        print("%s: worst %s %.3f%s" % (label, top, rs[top], flag), flush=True)
+        for k, v in rs.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+    print("worst ratios over %d cases (%.0f s; %d of them with voxels at the DRC clamp's threshold, compared with the oracle nudged to the "
+          "device's decisions): %s" % (len(only), time.time() - t0, explained, {k: round(v, 3) for k, v in sorted(worst.items())}))
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
