@@ -133,6 +133,38 @@ def one_case(seed, idx, rng=None, dry=False):
             notes.append("un-nudged oracle: worst %s %.3f; %d voxel(s) decided the other way at the DRC clamp's threshold (within %.1e relative "
                          "of it); against the oracle with THOSE voxels on the device's side:" % (max(rs, key=rs.get), max(rs.values()), flips, far))
             rs = rs2
+    if max(rs.values()) > 1.0:
+        # The `voxels` output comes from the saved W/H-smoothed grid through a stage kernel, the decision inside the ray-march
+        # kernels from their own D pass (another order of the same sum): a voxel within an ulp of the threshold can read "inside"
+        # in one and "outside" in the other.  Try every assignment of the few voxels that close to a threshold.
+        import itertools
+
+        eps = cfg.drc_logsum_clip_val
+        v = ref_vox.detach().double()
+        for window in (1e-5, 1e-4, 1e-3):   # (the device's Gaussians drop taps below 1e-8 of the kernel's mass: up to ~1e-3 of eps)
+            close_to = (((v - eps).abs() <= window * eps) | ((v - (1.0 - eps)).abs() <= window * (1.0 - eps))).nonzero().tolist()
+            if close_to:
+                break
+        if 0 < len(close_to) <= 8:
+            best = {}
+            for bits in itertools.product((0, 1), repeat=len(close_to)):
+                nudge = torch.zeros_like(v)
+                for ix, keep in zip(close_to, bits):
+                    val = v[tuple(ix)].item()
+                    low = abs(val - eps) <= abs(val - (1.0 - eps))
+                    th = eps if low else 1.0 - eps
+                    inward = (1.0 + 1e-9) if low else (1.0 - 1e-9)
+                    nudge[tuple(ix)] = th * (inward if keep else 2.0 - inward) - val
+                rs2, _ = against_the_oracle(nudge)
+                # the fused call and the reference-signature call decide in different kernels: each takes its own best assignment
+                for group in (lambda k: k.startswith("plain"), lambda k: not k.startswith("plain")):
+                    part = {k: x for k, x in rs2.items() if group(k)}
+                    have = {k: x for k, x in best.items() if group(k)}
+                    if not have or max(part.values()) < max(have.values()):
+                        best.update(part)
+            notes.append("un-nudged oracle: worst %s %.3f; %d voxel(s) within %.0e relative of a threshold of the DRC clamp; against the oracle "
+                         "with the best of the %d assignments of pass / block to them (per call):" % (max(rs, key=rs.get), max(rs.values()), len(close_to), window, 2 ** len(close_to)))
+            rs = best
     return label, rs, notes
 
 
