@@ -80,23 +80,40 @@ def one_case(seed, idx, rng=None, dry=False):
     _, q, s, _, t, f = O.synth_inputs(B, 4, G, data_seed + 1, with_t=with_t, with_f=with_f)
     gt = O.synth_inputs(S, 1, G, data_seed + 2)[3]      # the silhouette is H x W whatever the depth
     w = torch.from_numpy((np.random.default_rng([seed, idx]) if sequential and shared else rng).standard_normal((B, G, G, 1)))
+    # one case in four (not in replays of the sequential stream): every cloud keeps a random subset of its stored point set,
+    # chosen on the device (pc_point_dropout, point_cloud_to.py:266-295, as DpcParams.point_index)
+    keep = float(rng.uniform(0.1, 0.9)) if (not sequential and N >= 16 and rng.integers(0, 4) == 0) else None
     if dry:
         return None, None, None
-    label = "case %3d: G=%d%s k=%d sigma=%.2f S=%d K=%d%s N=%d%s%s" % (
-        idx, G, "" if vz == G else " z=%d" % vz, ksz, sig, S, K, " shared" if shared else "", N, " t" if with_t else "", " f" if with_f else "")
+    label = "case %3d: G=%d%s k=%d sigma=%.2f S=%d K=%d%s N=%d%s%s%s" % (
+        idx, G, "" if vz == G else " z=%d" % vz, ksz, sig, S, K, " shared" if shared else "", N, " t" if with_t else "", " f" if with_f else "",
+        "" if keep is None else " keep=%.2f" % keep)
     leaf = lambda x: None if x is None else x.clone().requires_grad_(True)
     kern = O.smoothing_kernel(cfg, sig)
     d = lambda x: None if x is None else x.float().cuda().requires_grad_(True)
     cu = lambda x: None if x is None else x.float().cuda()
 
+    pidx, rows = None, None
+    if keep is not None:
+        pidx = R.point_dropout_indices(B, N, keep, torch.device("cuda"), torch.Generator(device="cuda").manual_seed(data_seed & 0xffff))
+        rows = pidx.long().cpu().unsqueeze(-1).expand(-1, -1, 3)
+    extra = {} if pidx is None else {"point_index": pidx}
+
+    def clouds(p):   # the clouds the reference would be handed: stored sets replicated over the candidates, then every cloud's subset
+        full = p.repeat_interleave(K, 0) if shared else p
+        return full if rows is None else full.gather(1, rows)
+
     # device: the fused loss call, and the reference's own signature with a weighted sum of the silhouette as the loss
     gp, gq, gs, gtt, gf = d(pc), d(q), d(s), d(t), d(f)
     loss, out, win = R.pointcloud_project_loss(cfg, gp, gq, gtt, None, R.smoothing_kernel(cfg, sig), scaling_factor=gs, focal_length=gf,
-                                               gt=gt.float().cuda(), num_candidates=K)
+                                               gt=gt.float().cuda(), num_candidates=K, **extra)
     loss.backward()
     gp2, gq2, gs2 = d(pc), d(q), d(s)
-    o2 = R.pointcloud_project_fast(cfg, gp2.repeat_interleave(K, 0) if shared else gp2, gq2, cu(t), None, R.smoothing_kernel(cfg, sig),
-                                   scaling_factor=gs2, focal_length=cu(f))
+    if pidx is None:
+        o2 = R.pointcloud_project_fast(cfg, gp2.repeat_interleave(K, 0) if shared else gp2, gq2, cu(t), None, R.smoothing_kernel(cfg, sig),
+                                       scaling_factor=gs2, focal_length=cu(f))
+    else:       # stored sets + index rows: the library replicates a shared set itself
+        o2 = R.pointcloud_project_fast(cfg, gp2, gq2, cu(t), None, R.smoothing_kernel(cfg, sig), scaling_factor=gs2, focal_length=cu(f), **extra)
     (o2["proj"] * w.float().cuda()).sum().backward()
     dev_vox = o2["voxels"].detach()
 
@@ -104,11 +121,11 @@ def one_case(seed, idx, rng=None, dry=False):
         O.DRC_CLAMP_NUDGE = nudge
         try:
             cp, cq, cs, ct, cf = leaf(pc), leaf(q), leaf(s), leaf(t), leaf(f)
-            ref = O.pointcloud_project_fast(cfg, cp.repeat_interleave(K, 0) if shared else cp, cq, ct, None, kern, scaling_factor=cs, focal_length=cf)
+            ref = O.pointcloud_project_fast(cfg, clouds(cp), cq, ct, None, kern, scaling_factor=cs, focal_length=cf)
             rloss, rwin = O.proj_loss_pose_candidates(gt, ref["proj"], K) if K > 1 else (((ref["proj"] - gt) ** 2).sum() / B, None)
             rloss.backward()
             cp2, cq2, cs2 = leaf(pc), leaf(q), leaf(s)
-            ref2 = O.pointcloud_project_fast(cfg, cp2.repeat_interleave(K, 0) if shared else cp2, cq2, t, None, kern, scaling_factor=cs2, focal_length=f)
+            ref2 = O.pointcloud_project_fast(cfg, clouds(cp2), cq2, t, None, kern, scaling_factor=cs2, focal_length=f)
             (ref2["proj"] * w).sum().backward()
         finally:
             O.DRC_CLAMP_NUDGE = None
@@ -141,8 +158,14 @@ def one_case(seed, idx, rng=None, dry=False):
 
         eps = cfg.drc_logsum_clip_val
         v = ref_vox.detach().double()
+        # ... of the point set (or cloud) whose d(points) is furthest off
+        cpw = leaf(pc)
+        O.pointcloud_project_fast(cfg, clouds(cpw), q, t, None, kern, scaling_factor=s, focal_length=f)["proj"].mul(w).sum().backward()
+        worst_set = int((gp2.grad.detach().double().cpu() - cpw.grad).abs().flatten(1).max(1).values.argmax())
+        mine = range(worst_set * K, worst_set * K + K) if shared else [worst_set]
         for window in (1e-5, 1e-4, 1e-3):   # (the device's Gaussians drop taps below 1e-8 of the kernel's mass: up to ~1e-3 of eps)
-            close_to = (((v - eps).abs() <= window * eps) | ((v - (1.0 - eps)).abs() <= window * (1.0 - eps))).nonzero().tolist()
+            hit = ((v - eps).abs() <= window * eps) | ((v - (1.0 - eps)).abs() <= window * (1.0 - eps))
+            close_to = [ix for ix in hit.nonzero().tolist() if ix[0] in mine]
             if close_to:
                 break
         if 0 < len(close_to) <= 8:
