@@ -68,6 +68,8 @@ def one_case(seed, idx, rng=None, dry=False):
     B = S * K
     shared = K > 1 and bool(rng.integers(0, 2))        # the candidates of a sample share its point set
     N = int(rng.integers(1, 2500))
+    if not sequential and S <= 2 and rng.integers(0, 4) == 0:
+        N = int(rng.integers(16385, 30000))             # beyond the flat record table (64 chunks): the wave-per-chunk loops, dense grids
     with_t, with_f = bool(rng.integers(0, 2)), bool(rng.integers(0, 4) == 0)
     vz = int(rng.choice([G, G, G, max(8, G // 2)]))
     cfg = O.Cfg(vox_size=G, pc_gauss_kernel_size=ksz)
