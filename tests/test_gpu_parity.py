@@ -2114,6 +2114,29 @@ def test_pose_gradient_against_the_reference_and_its_exact_sum(R, O):
     close(gs.grad, refs[False][4], TOL, "pose gradient case: ds vs the raw reference")
 
 
+def test_randomised_shapes_vs_oracle(R, O):
+    """Forty random configurations out of tools/fuzz_parity.py (grid side 16..64, a z side of its own, 1..21 taps, sigma 0.25..3.2,
+    1/2/4 pose candidates, shared point sets, per-cloud point dropout, translation / focal-length inputs, up to 48 clouds and
+    30 000 points): the fused loss call AND the reference-signature call against the oracle by the rule.  A case in which the device
+    decided a voxel the other way at the DRC clamp's threshold is judged against the oracle with that voxel on the device's side
+    (test_drc_clamp_threshold_flip_is_bounded_and_explained; the tool's sweeps of 2000 cases: profiles/r04_fuzz_parity.txt)."""
+    import importlib.util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(root, "tools", "fuzz_parity.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    worst = {}
+    for idx in range(40):
+        label, rs, notes = fuzz.one_case(7, idx)
+        top = max(rs, key=rs.get)
+        assert rs[top] <= 1.0, "%s: %s %.3f x the rule %s" % (label, top, rs[top], notes)
+        for k, v in rs.items():
+            worst[k] = max(worst.get(k, 0.0), v)
+    for k, v in sorted(worst.items()):
+        ERRORS.append(("randomised shapes (40 cases), worst error / bound: " + k, v * TOL, 1.0))
+
+
 def test_zz_error_report():
     """Not a check: writes the worst observed error per quantity to gpurun_out/ for DESIGN.md."""
     worst = {}
