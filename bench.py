@@ -233,11 +233,12 @@ def full_step_main(args, rank, world, local):
     pose candidates -> 128 clouds of 8000 points into 64^3; networks + renderer + loss + backward + Adam, fp32, eager),
     weak scaling: every rank owns 8 objects, the parameter gradients (133 MB) are summed over RCCL in buckets launched from
     autograd hooks while the backward is still running (dpc.render.parallel.OverlappedGradAllReduce)."""
+    dist_on = world > 1 or args.rccl_at_one_rank   # one rank: the collectives of the N-rank line over RCCL, for a one-GPU box
     if args.rehearse_on_one_gpu:
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo" if args.rehearse_on_one_gpu else "nccl",
                                 **({} if args.rehearse_on_one_gpu else {"device_id": device}))
@@ -259,7 +260,7 @@ def full_step_main(args, rank, world, local):
     step = TrainStep(cfg, device, device_dropout=True, capturable=args.captured and world == 1 and not args.captured_compute)
     torch.cuda.manual_seed(4321 + rank)      # ... but every rank draws its OWN dropout subsets (device generator)
     sync = None
-    if world > 1 or args.captured_compute:
+    if dist_on or args.captured_compute:
         sync = OverlappedGradAllReduce(step.nets.parameters(), bucket_mb=32, overlap=not args.no_overlap)
         step.grad_sync, step.sync_samples = sync, (cfg.batch_size, cfg.batch_size * world)
     nimg = cfg.batch_size * cfg.step_size
@@ -274,7 +275,7 @@ def full_step_main(args, rank, world, local):
     for _ in range(args.warmup):
         step(images, masks)
     torch.cuda.synchronize(device)
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
@@ -282,13 +283,13 @@ def full_step_main(args, rank, world, local):
         loss = step(images, masks)
     torch.cuda.synchronize(device)
     mine = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize(device)
     wall = time.perf_counter() - t0
     times = torch.tensor([wall, mine], device=device, dtype=torch.float64)
     per_rank = [times.clone() for _ in range(world)]
-    if world > 1:
+    if dist_on:
         dist.all_gather(per_rank, times)
     wall = max(float(t[0]) for t in per_rank)
     comm = None
@@ -321,7 +322,7 @@ def full_step_main(args, rank, world, local):
             "allreduce_alone_ms": None if comm is None else 1e3 * comm,
             "allreduce_exposed_ms": None if sync is None else 1e3 * sync.exposed_seconds / max(1, sync.steps),
             "loss": float(loss)}))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
@@ -363,6 +364,9 @@ def main():
                          "line); plain: the reference's own call sequence, pointcloud_project_fast then the loss in torch")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single-GPU box: every rank uses cuda:0 and the collectives run over gloo")
+    ap.add_argument("--rccl-at-one-rank", action="store_true",
+                    help="with one rank under torch.distributed.run: initialise RCCL anyway and run the barriers and all-reduces "
+                         "of the N-rank line (what a one-GPU box can execute of the --gpus N code)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -388,11 +392,12 @@ def main():
         raise SystemExit("--gpus %d but this node shows %d device(s)" % (world, torch.cuda.device_count()))
     if args.config == "c3" or args.full_step:
         return full_step_main(args, rank, world, local)
+    dist_on = world > 1 or args.rccl_at_one_rank   # as in full_step_main
     if args.rehearse_on_one_gpu:
         local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse_on_one_gpu:
             dist.init_process_group("gloo")
@@ -554,7 +559,7 @@ def main():
         for i in range(args.warmup):
             run_step(i)
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(device)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -564,17 +569,17 @@ def main():
             run_step(i)
         ev1.record(side)
         torch.cuda.synchronize(device)
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(device)
         wall = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1) if not lanes else wall * 1e3   # several streams: the events of one do not bracket the others
 
         tt = torch.tensor([wall], device=device, dtype=torch.float64)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         loss_t = last[0].detach().clone().reshape(1) if last[0] is not None else torch.zeros(1, device=device)
-        if world > 1:
+        if dist_on:
             dist.all_reduce(loss_t, op=dist.ReduceOp.SUM)  # the only exchange: the final step's loss, once
         wall = tt.item()
 
@@ -675,7 +680,7 @@ def main():
             extras["forward_only_us"] = {"median": fw[len(fw) // 2], "best": fw[0]}
 
     if rank != 0:
-        if world > 1:
+        if dist_on:
             dist.destroy_process_group()
         return
 
@@ -732,7 +737,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:  # the CPU leg is a single-GPU-run item (rank 0 at N=1 only)
         out["cpu_baseline"] = cpu_baseline()
     print(json.dumps(out))
-    if world > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
